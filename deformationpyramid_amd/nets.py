@@ -1,0 +1,125 @@
+"""Deformation pyramid: host-side mirror of the reference's model/nets.py interface.
+
+Public surface kept from the reference (/root/reference/model/nets.py:10-62):
+
+    Deformation_Pyramid(depth, width, device, k0, m, rotation_format,
+                        nonrigidity_est=False, motion='SE3')
+        .pyramid[i]            per-level nn.Module exposing .parameters()/.named_parameters()
+        .n_hierarchy
+        .warp(x, max_level=None, min_level=0) -> (x', {level: (x_level, nonrigidity|None)})
+        .gradient_setup(optimized_level)
+
+What is different underneath: every level's parameters live in ONE flat float32 block
+(layout.py / include/ndp_types.h) and all m blocks are rows of a single [m, Pmax] tensor in
+HBM; the per-name nn.Parameters are views into it.  `warp` runs the hand-written HIP level
+kernels (csrc/) through torch.autograd.Function wrappers, so callers that own their Adam loop
+(shape_transfer.py:116-157 style) keep working.  There is no PyTorch fallback: on a CUDA/HIP
+device the native library must be loaded; on CPU tensors `warp` raises.
+
+Initialisation replays the reference's RNG consumption exactly (nets.py:75-109,180-183):
+default nn.Linear init for weights and biases in module-registration order, then
+xavier_uniform_ on every matrix, for all m levels up front, on the CPU generator.
+"""
+import torch
+import torch.nn as nn
+
+from .layout import LayerDesc
+
+
+def _init_level_flat(desc: LayerDesc, depth: int) -> torch.Tensor:
+    """Build one level's parameters with the same torch calls, in the same order, as
+    NDPLayer.__init__ + _reset_parameters (nets.py:67-109,180-183); return the flat block."""
+    W = desc.width
+    mods = [nn.Linear(6, W)]                                   # self.input[0]
+    mods += [nn.Linear(W, W) for _ in range(depth - 1)]        # self.mlp.pts_linears
+    if desc.n_rot:
+        mods.append(nn.Linear(W, desc.n_rot))                  # self.rot_brach
+    if desc.motion == "Sim3":
+        mods.append(nn.Linear(W, 1))                           # self.s_branch
+    mods.append(nn.Linear(W, 3))                               # self.trn_branch
+    if desc.nonrigidity:
+        mods.append(nn.Linear(W, 1))                           # self.nr_branch
+    for mod in mods:                                           # _reset_parameters
+        nn.init.xavier_uniform_(mod.weight)
+    flat = torch.empty(desc.param_count, dtype=torch.float32)
+    tensors = []
+    for mod in mods:
+        tensors += [mod.weight.detach(), mod.bias.detach()]
+    slices = desc.named_slices()
+    assert len(slices) == len(tensors)
+    for (name, off, shape), t in zip(slices, tensors):
+        assert tuple(t.shape) == tuple(shape), (name, t.shape, shape)
+        flat[off:off + t.numel()] = t.reshape(-1)
+    return flat
+
+
+class NDPLevel(nn.Module):
+    """One pyramid level.  Parameters are views into a row of the pyramid's flat store and
+    carry the reference's names (input.0.weight, mlp.pts_linears.0.weight, rot_brach.weight, ...)."""
+
+    def __init__(self, desc: LayerDesc, level: int, k0: int, flat_row: torch.Tensor):
+        super().__init__()
+        self.desc = desc
+        self.level = level
+        self.k0 = k0
+        self.m = level + 1                 # reference attribute name (nets.py:71)
+        self.mlp_scale = desc.mlp_scale
+        self.flat = flat_row               # [P] view, shares storage with the store
+        self._names = []
+        for name, off, shape in desc.named_slices():
+            n = 1
+            for s in shape:
+                n *= s
+            p = nn.Parameter(flat_row[off:off + n].view(shape), requires_grad=True)
+            reg = name.replace(".", "__")
+            self.register_parameter(reg, p)
+            self._names.append((name, reg))
+
+    def named_parameters(self, *a, **k):
+        # expose the reference's dotted names
+        for name, reg in self._names:
+            yield name, getattr(self, reg)
+
+    def parameters(self, recurse=True):
+        for _, p in self.named_parameters():
+            yield p
+
+    def forward(self, x):
+        from .ops import level_warp
+        return level_warp(self, x)
+
+
+class Deformation_Pyramid:
+    def __init__(self, depth, width, device, k0, m, rotation_format, nonrigidity_est=False, motion='SE3'):
+        assert motion in ["Sim3", "SE3", "sflow"]
+        self.depth, self.width, self.k0 = depth, width, k0
+        self.n_hierarchy = m
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        self.descs = [
+            LayerDesc(width=width, n_hidden=depth - 1, motion=motion, rotfmt=rotation_format,
+                      nonrigidity=bool(nonrigidity_est) and (i != 0))     # nets.py:26
+            for i in range(m)
+        ]
+        self.pmax = max(d.param_count for d in self.descs) if m else 0
+        # all levels are initialised on the CPU generator first (nets.py:20-30), then moved
+        store = torch.zeros(m, self.pmax, dtype=torch.float32)
+        for i, d in enumerate(self.descs):
+            store[i, :d.param_count] = _init_level_flat(d, depth)
+        self.store = store.to(self.device)
+        self.pyramid = [NDPLevel(d, i, k0, self.store[i, :d.param_count]) for i, d in enumerate(self.descs)]
+
+    def warp(self, x, max_level=None, min_level=0):
+        if max_level is None:
+            max_level = self.n_hierarchy - 1
+        assert max_level < self.n_hierarchy, "more level than defined"
+        data = {}
+        for i in range(min_level, max_level + 1):
+            x, nonrigidity = self.pyramid[i](x)
+            data[i] = (x, nonrigidity)
+        return x, data
+
+    def gradient_setup(self, optimized_level):
+        assert optimized_level < self.n_hierarchy, "more level than defined"
+        for i in range(self.n_hierarchy):
+            for param in self.pyramid[i].parameters():
+                param.requires_grad = (i == optimized_level)

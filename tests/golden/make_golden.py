@@ -1,0 +1,421 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by RUNNING THE REFERENCE.
+
+This script is build-container tooling: it imports rabbityl/DeformationPyramid from
+/root/reference (read-only) and records numeric inputs/outputs only.  Nothing from the
+reference's source text is written anywhere; the .npz files hold numbers.  It never
+runs on the GPU box (/root/reference does not exist there) and nothing in the product
+imports it.
+
+The reference depends on packages this image lacks (pytorch3d, open3d, skimage,
+easydict, mayavi).  They are replaced by empty module stubs, except for
+pytorch3d.ops.knn.knn_points whose *semantics* (exact brute-force K=1 nearest
+neighbour, squared L2, differentiable distances) are supplied by a small torch
+stand-in below -- pytorch3d itself is un-vendored and un-pinned upstream
+(README.md:15-16), see DESIGN.md "oracle pinning".
+
+Usage:  python tests/golden/make_golden.py [--only F3,F4] [--bench-pairs 8]
+"""
+import argparse
+import collections
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# --------------------------------------------------------------------------- stubs
+def _knn_points(p1, p2, lengths1=None, lengths2=None, K=1, **kw):
+    """Exact brute-force 1-NN with squared-L2, lowest index on ties (torch stand-in)."""
+    assert K == 1
+    with torch.no_grad():
+        idx = []
+        for b in range(p1.shape[0]):
+            a, c = p1[b], p2[b]
+            best = torch.empty(a.shape[0], dtype=torch.int64)
+            for s in range(0, a.shape[0], 1024):
+                d = ((a[s:s + 1024, None, :] - c[None, :, :]) ** 2).sum(-1)
+                best[s:s + 1024] = d.argmin(dim=1)
+            idx.append(best)
+        idx = torch.stack(idx)[..., None]
+    nn = torch.gather(p2, 1, idx[..., 0, None].expand(-1, -1, p2.shape[-1]))
+    dists = ((p1 - nn) ** 2).sum(-1, keepdim=True)
+    return collections.namedtuple("KNN", "dists idx knn")(dists, idx, None)
+
+
+def install_stubs():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Pointclouds:  # only used in isinstance() checks
+        pass
+
+    class EasyDict(dict):
+        def __init__(self, d=None, **kw):
+            super().__init__()
+            for k, v in dict(d or {}, **kw).items():
+                self[k] = v
+
+        def __setitem__(self, k, v):
+            if isinstance(v, dict) and not isinstance(v, EasyDict):
+                v = EasyDict(v)
+            super().__setitem__(k, v)
+
+        __getattr__ = dict.__getitem__
+        __setattr__ = __setitem__
+
+    mod("pytorch3d")
+    mod("pytorch3d.ops")
+    mod("pytorch3d.ops.knn", knn_points=_knn_points, knn_gather=None)
+    mod("pytorch3d.structures")
+    mod("pytorch3d.structures.pointclouds", Pointclouds=Pointclouds)
+    sk = mod("skimage")
+    sk.io = mod("skimage.io")
+    mod("open3d")
+    mod("easydict", EasyDict=EasyDict)
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    return EasyDict
+
+
+# ------------------------------------------------------------------ synthetic pairs
+def synthetic_pair(p, n_total=16384, partial=True):
+    """SURVEY.md section 8(d) generator.  Mirrors deformationpyramid_amd.synthetic (kept
+    separate on purpose: this file must not import the product)."""
+    g = torch.Generator().manual_seed(1000 + p)
+    u = torch.rand(n_total, 3, generator=g, dtype=torch.float32) - 0.5
+    src = u[0::2].contiguous()
+    tgt_base = u[1::2].contiguous()
+    c, s = float(np.cos(0.3)), float(np.sin(0.3))
+    Rz = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    t = torch.tensor([0.1, 0.0, -0.05], dtype=torch.float32)
+
+    def phi(q):
+        return q + 0.05 * torch.sin(3.0 * q)
+
+    tgt = phi(tgt_base) @ Rz.T + t
+    flow_gt = phi(src) @ Rz.T + t - src
+    if partial:
+        tgt = tgt[tgt_base[:, 0] < 0.25].contiguous()
+        overlap = src[:, 0] < 0.25
+    else:
+        overlap = torch.ones(src.shape[0], dtype=torch.bool)
+    return src, tgt, flow_gt, overlap
+
+
+def ndp_config(EasyDict, **over):
+    cfg = dict(deformation_model="NDP", device=torch.device("cpu"), iters=500, lr=0.01,
+               max_break_count=15, break_threshold_ratio=0.001, w_reg=0.0, samples=2000,
+               m=9, k0=-8, depth=3, width=128, motion_type="SE3",
+               rotation_format="axis_angle", w_cd=0.0, trunc_cd=0.25)
+    cfg.update(over)
+    return EasyDict(cfg)
+
+
+def layer_params(layer):
+    """name -> float32 array, in module registration order."""
+    return {k: v.detach().numpy().copy() for k, v in layer.named_parameters()}
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# ------------------------------------------------------------------------ fixtures
+def F1_init(nets, **_):
+    out = {}
+    for tag, kw in {
+        "se3aa_m9": dict(m=9, rotation_format="axis_angle", motion="SE3"),
+        "sim3eu_m9": dict(m=9, rotation_format="euler", motion="Sim3"),
+        "se3aa_m10": dict(m=10, rotation_format="axis_angle", motion="SE3"),
+        "se3quat_nr_m3": dict(m=3, rotation_format="quaternion", motion="SE3", nonrigidity_est=True),
+        "sflow6d_m2": dict(m=2, rotation_format="6D", motion="sflow"),
+    }.items():
+        torch.manual_seed(0)
+        pyr = nets.Deformation_Pyramid(depth=3, width=128, device="cpu", k0=-8, **kw)
+        names, sums, asums, heads, shapes = [], [], [], [], []
+        for li, layer in enumerate(pyr.pyramid):
+            for k, v in layer.named_parameters():
+                a = v.detach().double().numpy().ravel()
+                names.append(f"{li}.{k}")
+                sums.append(a.sum())
+                asums.append(np.abs(a).sum())
+                h = np.zeros(8)
+                h[:min(8, a.size)] = a[:8]
+                heads.append(h)
+                shapes.append(list(v.shape) + [0] * (2 - v.dim()))
+        perm_a = torch.randperm(8192)[:16].numpy()
+        perm_b = torch.randperm(6100)[:16].numpy()
+        out[f"{tag}.names"] = np.array(names)
+        out[f"{tag}.sum"] = np.array(sums)
+        out[f"{tag}.abssum"] = np.array(asums)
+        out[f"{tag}.head8"] = np.array(heads)
+        out[f"{tag}.shape"] = np.array(shapes)
+        out[f"{tag}.perm8192"] = perm_a
+        out[f"{tag}.perm6100"] = perm_b
+    save("F1_init", **out)
+
+
+def F2_layer_forward(nets, **_):
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(256, 3, generator=g) - 0.5
+    out["x"] = x.numpy()
+    variants = {
+        "se3aa": dict(rotation_format="axis_angle", motion="SE3"),
+        "sim3eu": dict(rotation_format="euler", motion="Sim3"),
+        "sflow": dict(rotation_format="axis_angle", motion="sflow"),
+        "se3eu": dict(rotation_format="euler", motion="SE3"),
+        "sim3aa": dict(rotation_format="axis_angle", motion="Sim3"),
+    }
+    out["head_scale"] = np.float32(30.0)
+    out["seed"] = np.int64(11)
+    for tag, kw in variants.items():
+        torch.manual_seed(11)
+        pyr = nets.Deformation_Pyramid(depth=3, width=128, device="cpu", k0=-8, m=9, **kw)
+        for lvl in ((0, 4, 8) if tag in ("se3aa", "sim3eu") else (4,)):
+            layer = pyr.pyramid[lvl]
+            # make the warp non-trivial: scale head weights so the motion is O(0.1)
+            with torch.no_grad():
+                for k, v in layer.named_parameters():
+                    if "branch" in k or "brach" in k:
+                        v.mul_(30.0)
+            # weights are NOT stored: tests replay the seeded init (pinned by F1) and apply
+            # head_scale; the checksum below catches any drift of that replay.
+            out[f"{tag}.L{lvl}.wsum"] = np.float64(sum(v.double().abs().sum().item() for v in layer.parameters()))
+            y, data = pyr.warp(x, max_level=lvl, min_level=lvl)
+            out[f"{tag}.L{lvl}.out"] = y.detach().numpy()
+            # gradient of a fixed linear functional of the output wrt every parameter
+            coef = torch.linspace(-1.0, 1.0, 256 * 3).reshape(256, 3)
+            for p in layer.parameters():
+                p.grad = None
+            (y * coef).sum().backward()
+            for k, v in layer.named_parameters():
+                out[f"{tag}.L{lvl}.grad.{k}"] = v.grad.numpy().copy()
+        # full pyramid inference on the same points
+        with torch.no_grad():
+            yfull, _ = pyr.warp(x)
+        out[f"{tag}.full_out"] = yfull.numpy()
+    save("F2_layer_forward", **out)
+
+
+def F3_chamfer(loss_mod, **_):
+    out = {}
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(300, 3, generator=g) - 0.5).requires_grad_(True)
+    y = (torch.rand(257, 3, generator=g) - 0.5) * 1.1 + 0.02
+    for tag, trunc in (("full", 1e9), ("trunc", 0.01)):
+        x.grad = None
+        L = loss_mod.compute_truncated_chamfer_distance(x[None], y[None], trunc=trunc)
+        L.backward()
+        nx = _knn_points(x.detach()[None], y[None])
+        ny = _knn_points(y[None], x.detach()[None])
+        out[f"{tag}.loss"] = np.float32(L.item())
+        out[f"{tag}.grad_x"] = x.grad.numpy().copy()
+        out[f"{tag}.idx_x"] = nx.idx[0, :, 0].numpy().astype(np.int32)
+        out[f"{tag}.idx_y"] = ny.idx[0, :, 0].numpy().astype(np.int32)
+        out[f"{tag}.d2_x"] = nx.dists[0, :, 0].numpy()
+        out[f"{tag}.d2_y"] = ny.dists[0, :, 0].numpy()
+    out["x"] = x.detach().numpy()
+    out["y"] = y.numpy()
+    save("F3_chamfer", **out)
+
+
+def _one_level_run(nets, loss_mod, kw, S, T, level, n_iter, seed, landmarks=None, trunc=1e9, keep_step1=False):
+    torch.manual_seed(seed)
+    pyr = nets.Deformation_Pyramid(depth=3, width=128, device="cpu", k0=-8, m=9, **kw)
+    layer = pyr.pyramid[level]
+    g = torch.Generator().manual_seed(seed + 1)
+    xs = torch.rand(S, 3, generator=g) - 0.5
+    c, s = float(np.cos(0.2)), float(np.sin(0.2))
+    Rz = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    if landmarks:
+        yt = (xs + 0.04 * torch.sin(4.0 * xs)) @ Rz.T + torch.tensor([0.03, -0.02, 0.01])
+    else:
+        yt = (torch.rand(T, 3, generator=g) - 0.5) @ Rz.T + torch.tensor([0.03, -0.02, 0.01])
+    rec = {"x": xs.numpy(), "y": yt.numpy(), "seed": np.int64(seed),
+           "wsum": np.float64(sum(v.double().abs().sum().item() for v in layer.parameters()))}
+    pyr.gradient_setup(optimized_level=level)
+    opt = torch.optim.Adam(layer.parameters(), lr=0.01)
+    losses = []
+    for it in range(n_iter):
+        w, _ = pyr.warp(xs, max_level=level, min_level=level)
+        if landmarks:
+            L = torch.mean(torch.sum((w - yt) ** 2, dim=-1))
+        else:
+            L = loss_mod.compute_truncated_chamfer_distance(w[None], yt[None], trunc=trunc)
+        losses.append(L.item())
+        opt.zero_grad()
+        L.backward()
+        if it == 0:
+            rec["warp0"] = w.detach().numpy().copy()
+            for k, v in layer.named_parameters():
+                rec[f"grad0.{k}"] = v.grad.numpy().copy()
+        opt.step()
+        if it == 2 or (it == 0 and keep_step1):
+            for k, v in layer.named_parameters():
+                rec[f"step{it + 1}.{k}"] = v.detach().numpy().copy()
+    w, _ = pyr.warp(xs, max_level=level, min_level=level)
+    rec["warp_final"] = w.detach().numpy()
+    rec["losses"] = np.array(losses, dtype=np.float64)
+    return rec
+
+
+def F4_F5_iteration(nets, loss_mod, **_):
+    out = {}
+    for tag, kw, lvl in (
+        ("se3aa.L0", dict(rotation_format="axis_angle", motion="SE3"), 0),
+        ("se3aa.L5", dict(rotation_format="axis_angle", motion="SE3"), 5),
+        ("sim3eu.L2", dict(rotation_format="euler", motion="Sim3"), 2),
+        ("sflow.L3", dict(rotation_format="axis_angle", motion="sflow"), 3),
+    ):
+        rec = _one_level_run(nets, loss_mod, kw, S=384, T=333, level=lvl, n_iter=20, seed=21,
+                             keep_step1=(tag == "se3aa.L0"))
+        for k, v in rec.items():
+            out[f"{tag}.{k}"] = v
+    save("F4F5_iteration", **out)
+
+
+def F9_landmarks(nets, loss_mod, **_):
+    out = {}
+    rec = _one_level_run(nets, loss_mod, dict(rotation_format="axis_angle", motion="SE3"),
+                         S=200, T=200, level=0, n_iter=8, seed=33, landmarks=True)
+    for k, v in rec.items():
+        out[f"ldmk.L0.{k}"] = v
+    save("F9_landmarks", **out)
+
+
+def _register_traced(reg_mod, EasyDict, cfg, src, tgt, landmarks=None, seed=0):
+    """Run the reference's register() recording every loss it evaluates, per level."""
+    trace = []
+    orig_cd = reg_mod.compute_truncated_chamfer_distance
+    orig_adam = reg_mod.optim.Adam
+
+    def cd(*a, **k):
+        v = orig_cd(*a, **k)
+        if not landmarks:
+            trace[-1].append(v.item())
+        return v
+
+    def adam(*a, **k):
+        trace.append([])
+        return orig_adam(*a, **k)
+
+    orig_mean = torch.mean
+
+    reg_mod.compute_truncated_chamfer_distance = cd
+    reg_mod.optim.Adam = adam
+    if landmarks:
+        def mean(t, *a, **k):
+            v = orig_mean(t, *a, **k)
+            if v.dim() == 0 and v.requires_grad:
+                trace[-1].append(v.item())
+            return v
+        reg_mod.torch.mean = mean
+    try:
+        torch.manual_seed(seed)
+        model = reg_mod.Registration(cfg)
+        model.load_pcds(src.numpy(), tgt.numpy(), landmarks=landmarks)
+        warped, _, _ = model.register()
+    finally:
+        reg_mod.compute_truncated_chamfer_distance = orig_cd
+        reg_mod.optim.Adam = orig_adam
+        reg_mod.torch.mean = orig_mean
+    return warped.detach(), trace
+
+
+def F7_end_to_end(reg_mod, loss_mod, EasyDict, **_):
+    out = {}
+    src, tgt, flow_gt, overlap = synthetic_pair(5, n_total=2048)
+    cfg = ndp_config(EasyDict, samples=256)
+    warped, trace = _register_traced(reg_mod, EasyDict, cfg, src, tgt, seed=0)
+    out["src"], out["tgt"] = src.numpy(), tgt.numpy()
+    out["flow_gt"], out["overlap"] = flow_gt.numpy(), overlap.numpy()
+    out["warped"] = warped.numpy()
+    out["iters_per_level"] = np.array([len(t) for t in trace])
+    out["loss_trace"] = np.array(sum(trace, []), dtype=np.float64)
+    m = loss_mod.compute_flow_metrics(warped - src, flow_gt, overlap)
+    out["metric_keys"] = np.array(list(m.keys()))
+    out["metric_vals"] = np.array(list(m.values()), dtype=np.float64)
+    save("F7_end_to_end", **out)
+
+
+def F8_metrics(loss_mod, **_):
+    g = torch.Generator().manual_seed(8)
+    gt = (torch.rand(500, 3, generator=g) - 0.5) * 0.3
+    flow = gt + torch.randn(500, 3, generator=g) * 0.03
+    flow[:40] = gt[:40]            # exact hits
+    gt[40:50] = 0.0                # zero-length GT (relative error blows up)
+    overlap = torch.rand(500, generator=g) < 0.7
+    m = loss_mod.compute_flow_metrics(flow, gt, overlap)
+    save("F8_metrics", flow=flow.numpy(), flow_gt=gt.numpy(), overlap=overlap.numpy(),
+         keys=np.array(list(m.keys())), vals=np.array(list(m.values()), dtype=np.float64))
+
+
+def F9b_lndp_end_to_end(reg_mod, EasyDict, **_):
+    src, tgt, flow_gt, overlap = synthetic_pair(9, n_total=2048)
+    g = torch.Generator().manual_seed(99)
+    idx = torch.randperm(src.shape[0], generator=g)[:120]
+    ls = src[idx]
+    lt = ls + flow_gt[idx] + 0.005 * torch.randn(120, 3, generator=g)
+    cfg = ndp_config(EasyDict, m=10, samples=256, w_cd=0.0)
+    warped, trace = _register_traced(reg_mod, EasyDict, cfg, src, tgt, landmarks=(ls, lt), seed=0)
+    save("F9b_lndp_end_to_end", src=src.numpy(), tgt=tgt.numpy(), ldmk_s=ls.numpy(), ldmk_t=lt.numpy(),
+         warped=warped.numpy(), iters_per_level=np.array([len(t) for t in trace]),
+         loss_trace=np.array(sum(trace, []), dtype=np.float64), flow_gt=flow_gt.numpy())
+
+
+def F10_benchmark(reg_mod, loss_mod, EasyDict, bench_pairs=8, **_):
+    """Reference metric rows on the synthetic benchmark (stand-in for 4DMatch-F, whose 14 GB
+    download is not available offline).  8192-pt pairs, NDP.yaml settings, one seed per pair."""
+    rows, iters, keys = [], [], None
+    for p in range(bench_pairs):
+        src, tgt, flow_gt, overlap = synthetic_pair(p)
+        cfg = ndp_config(EasyDict)
+        warped, trace = _register_traced(reg_mod, EasyDict, cfg, src, tgt, seed=p)
+        m = loss_mod.compute_flow_metrics(warped - src, flow_gt, overlap)
+        keys = list(m.keys())
+        rows.append(list(m.values()))
+        iters.append([len(t) for t in trace])
+        print(f"pair {p}: iters {iters[-1]}  full-epe {m['full-epe']:.3f} AccS {m['full-AccS']:.2f}", flush=True)
+    save("F10_benchmark", keys=np.array(keys), rows=np.array(rows, dtype=np.float64),
+         iters=np.array(iters), seeds=np.arange(bench_pairs))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--bench-pairs", type=int, default=8)
+    args = ap.parse_args()
+    EasyDict = install_stubs()
+    torch.set_num_threads(8)
+    import model.nets as nets
+    import model.loss as loss_mod
+    import model.registration as reg_mod
+    ctx = dict(nets=nets, loss_mod=loss_mod, reg_mod=reg_mod, EasyDict=EasyDict,
+               bench_pairs=args.bench_pairs)
+    todo = {
+        "F1": F1_init, "F2": F2_layer_forward, "F3": F3_chamfer, "F4": F4_F5_iteration,
+        "F7": F7_end_to_end, "F8": F8_metrics, "F9": F9_landmarks, "F9b": F9b_lndp_end_to_end,
+        "F10": F10_benchmark,
+    }
+    only = [s for s in args.only.split(",") if s]
+    for k, fn in todo.items():
+        if only and k not in only:
+            continue
+        print(f"--- {k}", flush=True)
+        fn(**ctx)
+
+
+if __name__ == "__main__":
+    main()

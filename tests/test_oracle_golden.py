@@ -1,0 +1,215 @@
+"""Pins the CPU oracle (oracle/ndp_oracle.c) and the host-side init replay against golden
+vectors captured FROM THE REFERENCE (tests/golden/make_golden.py, run in the build container).
+
+These are `not gpu` tests.  Tolerances are float32 round-off class: the reference's sgemm and
+the oracle's fmaf chains sum in different orders.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ndp_oracle as O
+from tests._helpers import VARIANTS, seeded_pyramid, scale_heads, flat_from_named, wsum, rel_err
+
+K0 = -8
+
+
+def cdesc(d):
+    return O.make_desc(d.width, d.n_hidden, d.motion, d.rotfmt, d.nonrigidity, d.mlp_scale)
+
+
+# ----------------------------------------------------------------------------- F1: init replay
+@pytest.mark.parametrize("tag,kw", [
+    ("se3aa_m9", dict(m=9, rotation_format="axis_angle", motion="SE3")),
+    ("sim3eu_m9", dict(m=9, rotation_format="euler", motion="Sim3")),
+    ("se3aa_m10", dict(m=10, rotation_format="axis_angle", motion="SE3")),
+    ("se3quat_nr_m3", dict(m=3, rotation_format="quaternion", motion="SE3", nonrigidity_est=True)),
+    ("sflow6d_m2", dict(m=2, rotation_format="6D", motion="sflow")),
+])
+def test_F1_init_replays_reference_rng(golden, tag, kw):
+    g = golden("F1_init")
+    pyr = seeded_pyramid(0, **kw)
+    names, sums, asums, heads = [], [], [], []
+    for li, layer in enumerate(pyr.pyramid):
+        for k, v in layer.named_parameters():
+            a = v.detach().double().numpy().ravel()
+            names.append(f"{li}.{k}")
+            sums.append(a.sum())
+            asums.append(np.abs(a).sum())
+            h = np.zeros(8)
+            h[:min(8, a.size)] = a[:8]
+            heads.append(h)
+    assert names == list(g[f"{tag}.names"])
+    np.testing.assert_array_equal(np.array(heads), g[f"{tag}.head8"])          # bit-exact
+    np.testing.assert_allclose(np.array(sums), g[f"{tag}.sum"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.array(asums), g[f"{tag}.abssum"], rtol=1e-12)
+    # the RNG stream continues identically after construction (registration.py:156-157)
+    np.testing.assert_array_equal(torch.randperm(8192)[:16].numpy(), g[f"{tag}.perm8192"])
+    np.testing.assert_array_equal(torch.randperm(6100)[:16].numpy(), g[f"{tag}.perm6100"])
+
+
+def test_param_counts_match_survey():
+    assert seeded_pyramid(0, m=1, **VARIANTS["se3aa"]).descs[0].param_count == 34694
+    assert seeded_pyramid(0, m=1, **VARIANTS["sim3eu"]).descs[0].param_count == 34823
+
+
+# ------------------------------------------------------------------- F2: level forward + grads
+def _f2_pyramid(g, tag):
+    pyr = seeded_pyramid(int(g["seed"]), **VARIANTS[tag])
+    levels = (0, 4, 8) if tag in ("se3aa", "sim3eu") else (4,)
+    for lvl in levels:
+        scale_heads(pyr, lvl, float(g["head_scale"]))
+        assert abs(wsum(pyr, lvl) - float(g[f"{tag}.L{lvl}.wsum"])) < 1e-6 * float(g[f"{tag}.L{lvl}.wsum"])
+    return pyr, levels
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_F2_level_forward_and_grads(golden, tag):
+    g = golden("F2_layer_forward")
+    pyr, levels = _f2_pyramid(g, tag)
+    x = g["x"]
+    coef = np.linspace(-1.0, 1.0, 256 * 3, dtype=np.float32).reshape(256, 3)
+    coef = torch.linspace(-1.0, 1.0, 256 * 3).reshape(256, 3).numpy()
+    for lvl in levels:
+        d = pyr.descs[lvl]
+        params = pyr.store[lvl, :d.param_count].numpy()
+        out = O.level_fwd(cdesc(d), params, lvl, K0, x)
+        np.testing.assert_allclose(out, g[f"{tag}.L{lvl}.out"], rtol=0, atol=2e-6)
+        grads = O.level_bwd(cdesc(d), params, lvl, K0, x, coef)
+        for name, off, shape in d.named_slices():
+            ref = g[f"{tag}.L{lvl}.grad.{name}"]
+            got = grads[off:off + ref.size].reshape(ref.shape)
+            assert rel_err(got, ref) < 1e-4, (tag, lvl, name, rel_err(got, ref))  # cancelling sums, fp32 order
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_F2_full_pyramid_inference(golden, tag):
+    g = golden("F2_layer_forward")
+    pyr, _ = _f2_pyramid(g, tag)
+    descs = [cdesc(d) for d in pyr.descs]
+    params_all = np.concatenate([pyr.store[i, :d.param_count].numpy() for i, d in enumerate(pyr.descs)])
+    out = O.pyramid_fwd(descs, K0, params_all, g["x"])
+    np.testing.assert_allclose(out, g[f"{tag}.full_out"], rtol=0, atol=5e-6)
+
+
+# ------------------------------------------------------------------------------- F3: Chamfer
+@pytest.mark.parametrize("tag,trunc", [("full", 1e9), ("trunc", 0.01)])
+def test_F3_chamfer(golden, tag, trunc):
+    g = golden("F3_chamfer")
+    r = O.chamfer(g["x"], g["y"], trunc=trunc)
+    np.testing.assert_array_equal(r["idx_x"], g[f"{tag}.idx_x"])              # bit-exact indices
+    np.testing.assert_array_equal(r["idx_y"], g[f"{tag}.idx_y"])
+    np.testing.assert_allclose(r["d2x"], g[f"{tag}.d2_x"], rtol=3e-7, atol=0)
+    np.testing.assert_allclose(r["d2y"], g[f"{tag}.d2_y"], rtol=3e-7, atol=0)
+    assert abs(float(r["loss"]) - float(g[f"{tag}.loss"])) < 2e-6 * float(g[f"{tag}.loss"])
+    np.testing.assert_allclose(r["gx"], g[f"{tag}.grad_x"], rtol=0, atol=2e-6 * np.abs(g[f"{tag}.grad_x"]).max())
+    if tag == "trunc":
+        assert (g["trunc.d2_x"] >= trunc).any() and (g["trunc.d2_x"] < trunc).any()
+
+
+# ---------------------------------------------------------- F4/F5: one iteration, 20 iterations
+ITER_CASES = [("se3aa.L0", "se3aa", 0), ("se3aa.L5", "se3aa", 5), ("sim3eu.L2", "sim3eu", 2), ("sflow.L3", "sflow", 3)]
+
+
+def _run_level(g, tag, var, lvl, n_iter, landmarks=False, fixture_prefix=None):
+    pre = fixture_prefix or tag
+    pyr = seeded_pyramid(int(g[f"{pre}.seed"]), **VARIANTS[var])
+    assert abs(wsum(pyr, lvl) - float(g[f"{pre}.wsum"])) < 1e-6 * float(g[f"{pre}.wsum"])
+    d = pyr.descs[lvl]
+    cd = cdesc(d)
+    p = pyr.store[lvl, :d.param_count].numpy().copy()
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    x, y = g[f"{pre}.x"], g[f"{pre}.y"]
+    rec = dict(losses=[])
+    for it in range(n_iter):
+        w = O.level_fwd(cd, p, lvl, K0, x)
+        if landmarks:
+            L, gx = O.landmark(w, y)
+        else:
+            r = O.chamfer(w, y)
+            L, gx = r["loss"], r["gx"]
+        rec["losses"].append(float(L))
+        grads = O.level_bwd(cd, p, lvl, K0, x, gx)
+        if it == 0:
+            rec["warp0"], rec["grad0"] = w, grads.copy()
+        O.adam(p, grads, m, v, it + 1)
+        if it in (0, 2):
+            rec[f"step{it + 1}"] = p.copy()
+    rec["warp_final"] = O.level_fwd(cd, p, lvl, K0, x)
+    return d, rec
+
+
+@pytest.mark.parametrize("tag,var,lvl", ITER_CASES)
+def test_F4_one_iteration(golden, tag, var, lvl):
+    g = golden("F4F5_iteration")
+    d, rec = _run_level(g, tag, var, lvl, n_iter=3)
+    np.testing.assert_allclose(rec["warp0"], g[f"{tag}.warp0"], rtol=0, atol=1e-6)
+    assert abs(rec["losses"][0] - g[f"{tag}.losses"][0]) < 2e-6 * g[f"{tag}.losses"][0]
+    for name, off, shape in d.named_slices():
+        ref = g[f"{tag}.grad0.{name}"]
+        got = rec["grad0"][off:off + ref.size].reshape(ref.shape)
+        assert rel_err(got, ref) < 1e-4, (name, rel_err(got, ref))
+        # Adam: step 1 moves every parameter by ~lr*sign(g) whatever |g| is, so parameters whose
+        # gradient is round-off noise can legitimately differ by 2*lr; compare where |g| is material.
+        ref3 = g[f"{tag}.step3.{name}"]
+        got3 = rec["step3"][off:off + ref3.size].reshape(ref3.shape)
+        mask = np.abs(ref) > 1e-3 * np.abs(ref).max()
+        assert np.abs(got3 - ref3)[mask].max() < 2e-4, name
+        if tag == "se3aa.L0":
+            ref1 = g[f"{tag}.step1.{name}"]
+            got1 = rec["step1"][off:off + ref1.size].reshape(ref1.shape)
+            assert np.abs(got1 - ref1)[mask].max() < 1e-5, name
+
+
+@pytest.mark.parametrize("tag,var,lvl", ITER_CASES)
+def test_F5_short_trajectory(golden, tag, var, lvl):
+    g = golden("F4F5_iteration")
+    _, rec = _run_level(g, tag, var, lvl, n_iter=20)
+    ref = g[f"{tag}.losses"]
+    got = np.array(rec["losses"])
+    assert abs(got[1] - ref[1]) < 1e-4 * ref[1]
+    assert np.abs(got - ref).max() < 1e-2 * ref.max()          # loosens to 1e-2 by step 20
+    assert np.abs(rec["warp_final"] - g[f"{tag}.warp_final"]).mean() < 5e-3
+
+
+def test_F9_landmark_iterations(golden):
+    g = golden("F9_landmarks")
+    d, rec = _run_level(g, "ldmk.L0", "se3aa", 0, n_iter=8, landmarks=True)
+    ref = g["ldmk.L0.losses"]
+    assert abs(rec["losses"][0] - ref[0]) < 2e-6 * ref[0]
+    assert np.abs(np.array(rec["losses"]) - ref).max() < 1e-2 * ref.max()
+    for name, off, shape in d.named_slices():
+        r0 = g[f"ldmk.L0.grad0.{name}"]
+        got = rec["grad0"][off:off + r0.size].reshape(r0.shape)
+        assert rel_err(got, r0) < 1e-4, name
+
+
+# ------------------------------------------------------------------- F6/F7: early stop + end to end
+def test_F6_stop_rule_replays_reference_iteration_counts(golden):
+    """Feed the reference's own loss trace to the oracle's stop rule: the per-level evaluation
+    counts must come out exactly (registration.py:226-232)."""
+    for fx in ("F7_end_to_end", "F9b_lndp_end_to_end"):
+        g = golden(fx)
+        trace, counts = g["loss_trace"], g["iters_per_level"]
+        pos = 0
+        for c in counts:
+            seg = trace[pos:pos + c]
+            brk, _, _ = O.stop_trace(seg)
+            if c < 500:
+                assert brk == c - 1, (fx, brk, c)        # the breaking evaluation is the last one
+            else:
+                assert brk == c
+            pos += c
+        assert pos == len(trace)
+
+
+def test_stop_rule_edges():
+    assert O.stop_trace([5e-5])[0] == 0                           # loss < 1e-4 -> immediate break
+    brk, bc, _ = O.stop_trace([1.0] * 40)
+    assert brk == 15 and bc == 15                                 # first eval vs 1e6 is not "small"
+    brk, bc, _ = O.stop_trace([1.0, 0.5] * 30)
+    assert brk == 60 and bc == 0
+    # the counter is cumulative, never reset by a good step
+    seq = [1.0] + [1.0] * 7 + [0.5] + [0.5] * 8
+    assert O.stop_trace(seq)[0] == len(seq) - 1
