@@ -1,0 +1,132 @@
+"""Loader and ctypes signatures for libndp_hip.so (the C ABI of include/ndp_hip.h).
+
+There is deliberately NO fallback: if the HIP library is missing or an entry point fails, the
+caller gets an exception.  `build()` compiles the library in-tree with hipcc for gfx950.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+from .layout import CLayerDesc
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+LIBPATH = os.path.join(LIBDIR, "libndp_hip.so")
+SOURCES = ["ndp_kernels.hip"]
+HEADERS = ["ndp_device.h", os.path.join("..", "..", "include", "ndp_hip.h"), os.path.join("..", "..", "include", "ndp_types.h")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+NDP_MAX_LEVELS = 16
+TILE = 64
+NHMAX = 16
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+
+
+class NdpError(RuntimeError):
+    pass
+
+
+class PairGeom(ctypes.Structure):
+    _fields_ = [("K", ctypes.c_int), ("S", ctypes.c_int), ("T", ctypes.c_int), ("pad", ctypes.c_int)]
+
+
+class PairState(ctypes.Structure):
+    _fields_ = [("level", ctypes.c_int), ("iter", ctypes.c_int), ("break_counter", ctypes.c_int),
+                ("adam_t", ctypes.c_int), ("cur", ctypes.c_int), ("decision", ctypes.c_int),
+                ("total_steps", ctypes.c_int), ("total_evals", ctypes.c_int), ("loss", ctypes.c_float),
+                ("step_level", ctypes.c_int), ("step_t", ctypes.c_int), ("pad", ctypes.c_int),
+                ("loss_prev", ctypes.c_double), ("evals_per_level", ctypes.c_int * NDP_MAX_LEVELS)]
+
+
+class Engine(ctypes.Structure):
+    _fields_ = [("desc", CLayerDesc), ("m", ctypes.c_int), ("k0", ctypes.c_int),
+                ("P", ctypes.c_int), ("p_stride", ctypes.c_int),
+                ("iters", ctypes.c_int), ("max_break_count", ctypes.c_int), ("early_stop", ctypes.c_int),
+                ("B", ctypes.c_int), ("G", ctypes.c_int), ("n_cap", ctypes.c_int), ("t_cap", ctypes.c_int),
+                ("break_threshold_ratio", ctypes.c_double),
+                ("w_cd", ctypes.c_float), ("trunc", ctypes.c_float),
+                ("adam_w1", ctypes.c_float), ("adam_b2", ctypes.c_float), ("adam_w2", ctypes.c_float),
+                ("adam_eps", ctypes.c_float),
+                ("geom", ctypes.c_void_p), ("state", ctypes.c_void_p), ("pts", ctypes.c_void_p),
+                ("ldmk_t", ctypes.c_void_p), ("tgt", ctypes.c_void_p), ("params", ctypes.c_void_p),
+                ("gpart", ctypes.c_void_p), ("adam_m", ctypes.c_void_p), ("adam_v", ctypes.c_void_p),
+                ("act", ctypes.c_void_p), ("heads", ctypes.c_void_p),
+                ("d2x", ctypes.c_void_p), ("idx_x", ctypes.c_void_p), ("d2y", ctypes.c_void_p),
+                ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p)]
+
+
+def _stale():
+    if not os.path.exists(LIBPATH):
+        return True
+    t = os.path.getmtime(LIBPATH)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 ... -> deformationpyramid_amd/lib/libndp_hip.so (in-tree)."""
+    if not force and not _stale():
+        return LIBPATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise NdpError("hipcc not found and libndp_hip.so is missing or stale")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIBPATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIBPATH
+
+
+_LIB = None
+V = ctypes.c_void_p
+I = ctypes.c_int
+F = ctypes.c_float
+DP = ctypes.POINTER(CLayerDesc)
+
+_SIGS = {
+    "ndp_level_fwd": [DP, V, I, I, V, I, V, V, V, V],
+    "ndp_level_bwd": [DP, V, I, I, V, I, V, V, V, V, I, I, V],
+    "ndp_grad_reduce": [V, I, I, I, V, V],
+    "ndp_pyramid_fwd": [DP, I, I, V, I, V, I, V, V, V],
+    "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],
+    "ndp_chamfer_l1_bwd": [V, I, V, I, F, V, V, V, V, V, V, V],
+    "ndp_landmark_mse_fwd_bwd": [V, V, I, V, V, V],
+    "ndp_adam_step": [V, V, V, V, I, F, F, F, F, F, F, V],
+    "ndp_engine_run": [ctypes.POINTER(Engine), I, I, V],
+}
+EXPORTS = ["ndp_version", "ndp_last_error"] + list(_SIGS)
+
+
+def lib(allow_build=True):
+    """Load the native library (building it first if the source is newer and hipcc exists)."""
+    global _LIB
+    if _LIB is None:
+        if allow_build and _stale() and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+            build()
+        if not os.path.exists(LIBPATH):
+            raise NdpError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = ctypes.CDLL(LIBPATH)
+        L.ndp_version.restype = I
+        L.ndp_last_error.restype = ctypes.c_char_p
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = I
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().ndp_last_error().decode(errors="replace")
+        raise NdpError(f"{what} failed (rc={rc}): {msg}")
+
+
+def stream_ptr(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,1044 @@
+// ndp_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels for the NDP per-pair optimisation
+// hot path, and the C ABI declared in include/ndp_hip.h.
+//
+// Design:
+//   * One workgroup = 256 threads = 4 wave64.  A tile is 64 points.  Wave w owns output columns
+//     [32w, 32w+32) of every 128-wide layer.
+//   * The two 128x128 weight matrices of a level are WEIGHT-STATIONARY IN REGISTERS: each lane
+//     holds its 64-float slice of W1 and of W2 in the v_mfma_f32_32x32x2_f32 B-operand layout
+//     (forward: W[o][k] slices; backward: the transposed slices) for the whole life of the
+//     workgroup, so the only per-MFMA operand fetch is one LDS read of the activation.
+//   * Activations move through two [64][132] LDS tiles (+4 float pad: ds_read_b128 of a column
+//     block is bank-conflict free).  fp32 in, fp32 accumulate: the MFMA result is bitwise an fmaf
+//     chain, which is what the 1e-4 parity budget needs.
+//   * The backward keeps dW1 and dW2 (2 x 128x128) in accumulator registers across all of the
+//     workgroup's tiles and writes ONE partial per workgroup; partials are folded in index order
+//     by the Adam kernel -- no float atomics anywhere, results are bit-reproducible.
+//   * The batched engine advances B independent pairs per launch, every pair at its own level and
+//     iteration; the early-stop rule runs on the device in double, so the host never syncs per
+//     iteration (the reference syncs three times: registration.py:226-232).
+//
+// Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fmaf only).
+#include "ndp_device.h"
+
+#include <cstdio>
+#include <cstring>
+
+#define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// ------------------------------------------------------------------------------------------------
+// LDS carve (floats).  All scratch lives in the dynamic region (16-byte aligned offsets).
+// ------------------------------------------------------------------------------------------------
+enum : int {
+    L_BUFA = 0,
+    L_BUFB = L_BUFA + 64 * NDP_LD,
+    L_PE = L_BUFB + 64 * NDP_LD,          // [6][64]
+    L_XS = L_PE + 6 * 64,                 // [64][4] level input x
+    L_WH = L_XS + 64 * 4,                 // [16][128] head weights
+    L_BH = L_WH + NDP_NHMAX * NDP_W,      // [16]
+    L_HO = L_BH + NDP_NHMAX,              // [64][16] head outputs / d_o
+    L_XW = L_HO + 64 * NDP_NHMAX,         // [64][4] warped x (backward)
+    L_G = L_XW + 64 * 4,                  // [4][64][4] gradient partials (backward)
+    L_RED = L_G + 4 * 64 * 4,             // [256] reduction scratch
+    L_TOTAL = L_RED + 256
+};
+static constexpr int kSmemBytes = L_TOTAL * 4;
+
+struct LevelJob {
+    const float *params;
+    float freq;
+    const float *x_in;
+    float *x_out;
+    float *act;        // [3][plane][128] or nullptr
+    float *heads;      // [plane][16] or nullptr
+    int n;             // live points
+    int plane;         // rows per activation plane (capacity, multiple of 64)
+    int n_tiles;       // live tiles = ceil(n / 64)
+    int tile0, tile_step;
+};
+
+// lane-resident slice of a 128x128 matrix in the 32x32x2 B-operand layout
+//   forward : w[ks] = W[32*wv + l31][64*h + ks]        (contraction index k = 64*h + ks)
+//   backward: w[ks] = W[64*h + ks][32*wv + l31]        (contraction index o = 64*h + ks)
+__device__ __forceinline__ void load_w_fwd(const float *W, int wv, int l31, int h, float (&w)[64]) {
+    const float4 *src = reinterpret_cast<const float4 *>(W + (32 * wv + l31) * NDP_W + 64 * h);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 v = src[i];
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+}
+__device__ __forceinline__ void load_w_bwd(const float *W, int wv, int l31, int h, float (&w)[64]) {
+    const float *src = W + (64 * h) * NDP_W + 32 * wv + l31;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) w[i] = src[i * NDP_W];
+}
+
+// out[p][32wv + l31] = sum_k in[p][k] * (w-slice)   for the 64 points of a tile; acc pre-loaded by caller
+__device__ __forceinline__ void tile_gemm_64x32(const float *in /*LDS [64][LD]*/, const float (&w)[64],
+                                                int l31, int h, f32x16 &acc0, f32x16 &acc1) {
+    const float *r0 = in + l31 * NDP_LD + 64 * h;
+    const float *r1 = r0 + 32 * NDP_LD;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(r0 + 4 * i);
+        const float4 a1 = *reinterpret_cast<const float4 *>(r1 + 4 * i);
+        acc0 = MFMA32(a0.x, w[4 * i], acc0);     acc1 = MFMA32(a1.x, w[4 * i], acc1);
+        acc0 = MFMA32(a0.y, w[4 * i + 1], acc0); acc1 = MFMA32(a1.y, w[4 * i + 1], acc1);
+        acc0 = MFMA32(a0.z, w[4 * i + 2], acc0); acc1 = MFMA32(a1.z, w[4 * i + 2], acc1);
+        acc0 = MFMA32(a0.w, w[4 * i + 3], acc0); acc1 = MFMA32(a1.w, w[4 * i + 3], acc1);
+    }
+}
+
+// C/D layout of v_mfma_f32_32x32x2_f32: reg r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
+__device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------------
+// Level forward  (nets.py:111-140)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob &job, float *sm) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *bufA = sm + L_BUFA, *bufB = sm + L_BUFB, *pe = sm + L_PE, *xs = sm + L_XS;
+    float *whs = sm + L_WH, *bhs = sm + L_BH, *ho = sm + L_HO;
+
+    const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
+    const float *P = job.params;
+    const float *W0 = P + ndp_off_W0(&dd), *b0 = P + ndp_off_b0(&dd);
+    const float *W1 = P + ndp_off_Wi(&dd, 1), *b1 = P + ndp_off_bi(&dd, 1);
+    const float *W2 = P + ndp_off_Wi(&dd, 2), *b2 = P + ndp_off_bi(&dd, 2);
+    const float *Wh = P + ndp_off_Wi(&dd, 3);      // == ndp_off_Wh for nonrigidity = 0
+    const float *bh = Wh + hc.nh * NDP_W;
+
+    // weight-stationary operands
+    float w1[64], w2[64];
+    load_w_fwd(W1, wv, l31, h, w1);
+    load_w_fwd(W2, wv, l31, h, w2);
+    const float bias1 = b1[32 * wv + l31], bias2 = b2[32 * wv + l31];
+    // layer 0: thread (o = t & 127, ph = t >> 7) handles 32 points
+    const int o0 = t & 127, ph = t >> 7;
+    float w0r[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) w0r[c] = W0[o0 * 6 + c];
+    const float bias0 = b0[o0];
+    for (int i = t; i < NDP_NHMAX * NDP_W; i += 256) whs[i] = (i < hc.nh * NDP_W) ? Wh[i] : 0.f;
+    if (t < NDP_NHMAX) bhs[t] = (t < hc.nh) ? bh[t] : 0.f;
+
+    for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
+        const int base = tile * NDP_TILE;
+        // ---- positional encoding (nets.py:164-177)
+        if (t < 64) {
+            const int p = base + t;
+            float x[3] = {0.f, 0.f, 0.f};
+            if (p < job.n) { x[0] = job.x_in[3 * p]; x[1] = job.x_in[3 * p + 1]; x[2] = job.x_in[3 * p + 2]; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float phs = x[a] * job.freq;
+                pe[(2 * a) * 64 + t] = sinf(phs);
+                pe[(2 * a + 1) * 64 + t] = cosf(phs);
+                xs[4 * t + a] = x[a];
+            }
+        }
+        __syncthreads();
+        // ---- layer 0 (6 -> 128, VALU) -> bufA
+        {
+            float *a0g = job.act ? job.act + (size_t)base * NDP_W : nullptr;
+#pragma unroll 4
+            for (int pp = 0; pp < 32; ++pp) {
+                const int p = 32 * ph + pp;
+                float acc = bias0;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) acc = fmaf(w0r[c], pe[c * 64 + p], acc);
+                acc = acc > 0.f ? acc : 0.f;
+                bufA[p * NDP_LD + o0] = acc;
+                if (a0g) a0g[p * NDP_W + o0] = acc;
+            }
+        }
+        __syncthreads();
+        // ---- layer 1 (MFMA) bufA -> bufB
+        {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = bias1; acc1[r] = bias1; }
+            tile_gemm_64x32(bufA, w1, l31, h, acc0, acc1);
+            float *a1g = job.act ? job.act + ((size_t)job.plane + base) * NDP_W : nullptr;
+            const int col = 32 * wv + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, h);
+                const float v0 = acc0[r] > 0.f ? acc0[r] : 0.f, v1 = acc1[r] > 0.f ? acc1[r] : 0.f;
+                bufB[row * NDP_LD + col] = v0;
+                bufB[(row + 32) * NDP_LD + col] = v1;
+                if (a1g) { a1g[row * NDP_W + col] = v0; a1g[(row + 32) * NDP_W + col] = v1; }
+            }
+        }
+        __syncthreads();
+        // ---- layer 2 (MFMA) bufB -> bufA
+        {
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = bias2; acc1[r] = bias2; }
+            tile_gemm_64x32(bufB, w2, l31, h, acc0, acc1);
+            float *a2g = job.act ? job.act + (2 * (size_t)job.plane + base) * NDP_W : nullptr;
+            const int col = 32 * wv + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, h);
+                const float v0 = acc0[r] > 0.f ? acc0[r] : 0.f, v1 = acc1[r] > 0.f ? acc1[r] : 0.f;
+                bufA[row * NDP_LD + col] = v0;
+                bufA[(row + 32) * NDP_LD + col] = v1;
+                if (a2g) { a2g[row * NDP_W + col] = v0; a2g[(row + 32) * NDP_W + col] = v1; }
+            }
+        }
+        __syncthreads();
+        // ---- heads (nets.py:117,125,146): thread (p = lane, jq = wave) computes heads jq, jq+4, ...
+        {
+            const float *hrow = bufA + lane * NDP_LD;
+            for (int j = wv; j < hc.nh; j += 4) {
+                const float *wr = whs + j * NDP_W;
+                float acc = bhs[j];
+#pragma unroll 8
+                for (int k4 = 0; k4 < 32; ++k4) {
+                    const float4 hv = *reinterpret_cast<const float4 *>(hrow + 4 * k4);
+                    const float4 wv4 = *reinterpret_cast<const float4 *>(wr + 4 * k4);
+                    acc = fmaf(wv4.x, hv.x, acc);
+                    acc = fmaf(wv4.y, hv.y, acc);
+                    acc = fmaf(wv4.z, hv.z, acc);
+                    acc = fmaf(wv4.w, hv.w, acc);
+                }
+                ho[lane * NDP_NHMAX + j] = hc.mlp_scale * acc;
+            }
+        }
+        __syncthreads();
+        // ---- warp (nets.py:119-129)
+        if (t < 64) {
+            const int p = base + t;
+            const float *o = ho + t * NDP_NHMAX;
+            if (job.heads) {
+#pragma unroll
+                for (int j = 0; j < NDP_NHMAX; j += 4)
+                    *reinterpret_cast<float4 *>(job.heads + (size_t)p * NDP_NHMAX + j) =
+                        *reinterpret_cast<const float4 *>(o + j);
+            }
+            if (p < job.n) {
+                PointHead c;
+                float out[3];
+                head_warp_fwd(hc, o, xs + 4 * t, c, out);
+                job.x_out[3 * p] = out[0]; job.x_out[3 * p + 1] = out[1]; job.x_out[3 * p + 2] = out[2];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Level backward (autograd of nets.py:111-140 wrt the level's parameters)
+// ------------------------------------------------------------------------------------------------
+struct BwdJob {
+    const float *params;
+    float freq;
+    const float *x_in;      // level input [n][3]
+    const float *act;       // [3][plane][128]
+    const float *heads;     // [plane][16]
+    const float *g;         // dL/dx_out [n][3]            (standalone mode)
+    float *gpart;           // this workgroup's partial [P]
+    int n, plane, n_tiles, tile0, tile_step;
+    // engine mode: gradient of the loss computed on the fly
+    const float *x_out;     // warped points [n][3]
+    const float *ldmk_t;    // [K][3]
+    const float *tgt;       // [T][3]
+    const float *d2x; const int *idx_x;   // [S]
+    const float *d2y; const int *idx_y;   // [t_cap] (-1 padded)
+    int K, S, T, t_cap;
+    float w_cd, trunc;
+};
+
+__device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] global*/, float *dst /*LDS [64][LD]*/) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = t + 256 * i;           // float4 index 0..2047
+        const int row = idx >> 5, c4 = idx & 31;
+        const float4 v = reinterpret_cast<const float4 *>(src)[idx];
+        *reinterpret_cast<float4 *>(dst + row * NDP_LD + 4 * c4) = v;
+    }
+}
+
+// dW[mt] += dz^T h   (rows o = 32*mt.., cols k = 32wv + l31), contraction over the tile's 64 points
+__device__ __forceinline__ void tile_outer_128x32(const float *dz /*LDS [64][LD]*/, const float *hin /*LDS [64][LD]*/,
+                                                  int wv, int l31, int h, f32x16 (&dW)[4]) {
+#pragma unroll 8
+    for (int ks = 0; ks < 32; ++ks) {
+        const int p = 32 * h + ks;
+        const float b = hin[p * NDP_LD + 32 * wv + l31];
+        const float *dr = dz + p * NDP_LD + l31;
+        const float a0 = dr[0], a1 = dr[32], a2 = dr[64], a3 = dr[96];
+        dW[0] = MFMA32(a0, b, dW[0]);
+        dW[1] = MFMA32(a1, b, dW[1]);
+        dW[2] = MFMA32(a2, b, dW[2]);
+        dW[3] = MFMA32(a3, b, dW[3]);
+    }
+}
+
+template <bool ENGINE>
+__device__ __forceinline__ void level_bwd_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *bufA = sm + L_BUFA, *bufB = sm + L_BUFB, *pe = sm + L_PE, *xs = sm + L_XS;
+    float *whs = sm + L_WH, *dO = sm + L_HO, *xw = sm + L_XW, *gs = sm + L_G;
+
+    const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
+    const float *P = job.params;
+    const float *W1 = P + ndp_off_Wi(&dd, 1), *W2 = P + ndp_off_Wi(&dd, 2);
+    const float *Wh = P + ndp_off_Wi(&dd, 3);
+
+    float w1t[64], w2t[64];
+    load_w_bwd(W1, wv, l31, h, w1t);
+    load_w_bwd(W2, wv, l31, h, w2t);
+    for (int i = t; i < NDP_NHMAX * NDP_W; i += 256) whs[i] = (i < hc.nh * NDP_W) ? Wh[i] : 0.f;
+
+    f32x16 dW1[4], dW2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dW1[m][r] = 0.f; dW2[m][r] = 0.f; }
+    const int o0 = t & 127, ph = t >> 7;      // VALU phases: thread (column o0, point half ph)
+    float gW0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gb0 = 0.f, gb1 = 0.f, gb2 = 0.f;
+    float gWh[NDP_NHMAX];
+#pragma unroll
+    for (int j = 0; j < NDP_NHMAX; ++j) gWh[j] = 0.f;
+    float gbh = 0.f;                           // thread t < 16 (ph = 0 only): bias of head t
+    __syncthreads();
+    float whk[NDP_NHMAX];                      // column o0 of the head matrix, pre-scaled rows
+#pragma unroll
+    for (int j = 0; j < NDP_NHMAX; ++j) whk[j] = whs[j * NDP_W + o0];
+
+    for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
+        const int base = tile * NDP_TILE;
+        // ---- T1: per point: x, pe, (engine: own-term gradient)
+        if (t < 64) {
+            const int p = base + t;
+            float x[3] = {0.f, 0.f, 0.f};
+            if (p < job.n) { x[0] = job.x_in[3 * p]; x[1] = job.x_in[3 * p + 1]; x[2] = job.x_in[3 * p + 2]; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float phs = x[a] * job.freq;
+                pe[(2 * a) * 64 + t] = sinf(phs);
+                pe[(2 * a + 1) * 64 + t] = cosf(phs);
+                xs[4 * t + a] = x[a];
+            }
+            float g[3] = {0.f, 0.f, 0.f};
+            if (ENGINE) {
+                float w[3] = {0.f, 0.f, 0.f};
+                if (p < job.n) { w[0] = job.x_out[3 * p]; w[1] = job.x_out[3 * p + 1]; w[2] = job.x_out[3 * p + 2]; }
+                xw[4 * t] = w[0]; xw[4 * t + 1] = w[1]; xw[4 * t + 2] = w[2];
+                if (p < job.K) {
+                    const float invK = 1.0f / (float)job.K;
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) g[a] = 2.0f * (w[a] - job.ldmk_t[3 * p + a]) * invK;
+                } else if (p < job.n && job.w_cd != 0.f) {
+                    const int i = p - job.K;
+                    const float d2 = job.d2x[i];
+                    if (!(d2 >= job.trunc)) {
+                        const float *yy = job.tgt + 3 * job.idx_x[i];
+                        const float inv = 1.0f / ((float)job.S * sqrtf(d2));
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) g[a] = (w[a] - yy[a]) * inv;
+                    }
+                }
+            } else if (p < job.n) {
+                g[0] = job.g[3 * p]; g[1] = job.g[3 * p + 1]; g[2] = job.g[3 * p + 2];
+            }
+            gs[4 * t] = g[0]; gs[4 * t + 1] = g[1]; gs[4 * t + 2] = g[2];
+        }
+        __syncthreads();
+        // ---- T2 (engine): contributions of target points whose nearest source point is in this tile,
+        //      ascending j inside each quarter, quarters folded in order (deterministic).
+        if (ENGINE) {
+            float acc[3] = {0.f, 0.f, 0.f};
+            const int i_self = base + lane - job.K;         // sample index of this thread's point
+            const bool live = (job.w_cd != 0.f) && (base + lane >= job.K) && (base + lane < job.n);
+            if (job.S > 0 && job.w_cd != 0.f) {
+                const int q4 = job.t_cap / 16;              // int4 groups per quarter
+                const int4 *iy4 = reinterpret_cast<const int4 *>(job.idx_y) + wv * q4;
+                const float wx = xw[4 * lane], wy = xw[4 * lane + 1], wz = xw[4 * lane + 2];
+                for (int j4 = 0; j4 < q4; ++j4) {
+                    const int4 v = iy4[j4];
+                    const int jb = 4 * (wv * q4 + j4);
+                    const int vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (live && vv[e] == i_self) {
+                            const int j = jb + e;
+                            const float d2 = job.d2y[j];
+                            if (!(d2 >= job.trunc)) {
+                                const float inv = 1.0f / ((float)job.T * sqrtf(d2));
+                                acc[0] = fmaf(wx - job.tgt[3 * j], inv, acc[0]);
+                                acc[1] = fmaf(wy - job.tgt[3 * j + 1], inv, acc[1]);
+                                acc[2] = fmaf(wz - job.tgt[3 * j + 2], inv, acc[2]);
+                            }
+                        }
+                    }
+                }
+            }
+            if (wv > 0) { float *gq = gs + wv * 256 + 4 * lane; gq[0] = acc[0]; gq[1] = acc[1]; gq[2] = acc[2]; }
+            __syncthreads();
+            if (wv == 0) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    float s = acc[a];
+                    s += gs[256 + 4 * lane + a];
+                    s += gs[512 + 4 * lane + a];
+                    s += gs[768 + 4 * lane + a];
+                    float gv = gs[4 * lane + a] + s;
+                    if (job.K > 0 && base + lane >= job.K) gv = job.w_cd * gv;     // registration.py:197
+                    gs[4 * lane + a] = gv;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- T3: head backward per point -> dO (pre-multiplied by mlp_scale)
+        if (t < 64) {
+            const int p = base + t;
+            float o[NDP_NHMAX];
+#pragma unroll
+            for (int j = 0; j < NDP_NHMAX; j += 4) {
+                const float4 v = *reinterpret_cast<const float4 *>(job.heads + (size_t)p * NDP_NHMAX + j);
+                o[j] = v.x; o[j + 1] = v.y; o[j + 2] = v.z; o[j + 3] = v.w;
+            }
+            // stage o in LDS (run-time row offsets), recompute the head forward, then its backward
+            float *orow = dO + t * NDP_NHMAX;
+#pragma unroll
+            for (int j = 0; j < NDP_NHMAX; ++j) orow[j] = o[j];
+            PointHead c;
+            float out[3];
+            head_warp_fwd(hc, orow, xs + 4 * t, c, out);
+            const float g[3] = {gs[4 * t], gs[4 * t + 1], gs[4 * t + 2]};
+            head_warp_bwd(hc, xs + 4 * t, c, g, orow);
+#pragma unroll
+            for (int j = 0; j < NDP_NHMAX; ++j) orow[j] = hc.mlp_scale * orow[j];
+        }
+        // ---- T4: h2 tile -> bufA
+        load_tile_to_lds(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufA);
+        __syncthreads();
+        // ---- T5: dh2 = dO . Wh ; dz2 = dh2 * [h2 > 0] -> bufB ; head-weight gradients
+        {
+#pragma unroll 2
+            for (int pp = 0; pp < 32; ++pp) {
+                const int p = 32 * ph + pp;
+                const float hv = bufA[p * NDP_LD + o0];
+                const float *dor = dO + p * NDP_NHMAX;
+                float dh = 0.f;
+#pragma unroll
+                for (int j4 = 0; j4 < NDP_NHMAX; j4 += 4) {
+                    const float4 d4 = *reinterpret_cast<const float4 *>(dor + j4);
+                    dh = fmaf(d4.x, whk[j4], dh);         gWh[j4] = fmaf(d4.x, hv, gWh[j4]);
+                    dh = fmaf(d4.y, whk[j4 + 1], dh);     gWh[j4 + 1] = fmaf(d4.y, hv, gWh[j4 + 1]);
+                    dh = fmaf(d4.z, whk[j4 + 2], dh);     gWh[j4 + 2] = fmaf(d4.z, hv, gWh[j4 + 2]);
+                    dh = fmaf(d4.w, whk[j4 + 3], dh);     gWh[j4 + 3] = fmaf(d4.w, hv, gWh[j4 + 3]);
+                }
+                bufB[p * NDP_LD + o0] = hv > 0.f ? dh : 0.f;
+            }
+            if (t < NDP_NHMAX) {
+                for (int p = 0; p < 64; ++p) gbh += dO[p * NDP_NHMAX + t];
+            }
+        }
+        __syncthreads();
+        // ---- T6: h1 tile -> bufA
+        load_tile_to_lds(job.act + ((size_t)job.plane + base) * NDP_W, bufA);
+        __syncthreads();
+        // ---- T7: dW2 += dz2^T h1 ; dh1 = dz2 W2 ; db2
+        f32x16 dh0a, dh1a;
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dh0a[r] = 0.f; dh1a[r] = 0.f; }
+            tile_outer_128x32(bufB, bufA, wv, l31, h, dW2);
+            tile_gemm_64x32(bufB, w2t, l31, h, dh0a, dh1a);
+#pragma unroll 8
+            for (int pp = 0; pp < 32; ++pp) gb2 += bufB[(32 * ph + pp) * NDP_LD + o0];
+        }
+        __syncthreads();
+        // ---- T8: dz1 = dh1 * [h1 > 0] -> bufB
+        {
+            const int col = 32 * wv + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, h);
+                bufB[row * NDP_LD + col] = bufA[row * NDP_LD + col] > 0.f ? dh0a[r] : 0.f;
+                bufB[(row + 32) * NDP_LD + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? dh1a[r] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- T9: h0 tile -> bufA
+        load_tile_to_lds(job.act + (size_t)base * NDP_W, bufA);
+        __syncthreads();
+        // ---- T10: dW1 += dz1^T h0 ; dh0 = dz1 W1 ; db1
+        {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dh0a[r] = 0.f; dh1a[r] = 0.f; }
+            tile_outer_128x32(bufB, bufA, wv, l31, h, dW1);
+            tile_gemm_64x32(bufB, w1t, l31, h, dh0a, dh1a);
+#pragma unroll 8
+            for (int pp = 0; pp < 32; ++pp) gb1 += bufB[(32 * ph + pp) * NDP_LD + o0];
+        }
+        __syncthreads();
+        // ---- T11: dz0 = dh0 * [h0 > 0] -> bufB
+        {
+            const int col = 32 * wv + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, h);
+                bufB[row * NDP_LD + col] = bufA[row * NDP_LD + col] > 0.f ? dh0a[r] : 0.f;
+                bufB[(row + 32) * NDP_LD + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? dh1a[r] : 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- T12: dW0 += dz0^T pe ; db0
+        {
+#pragma unroll 4
+            for (int pp = 0; pp < 32; ++pp) {
+                const int p = 32 * ph + pp;
+                const float z = bufB[p * NDP_LD + o0];
+                gb0 += z;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) gW0[c] = fmaf(z, pe[c * 64 + p], gW0[c]);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: one partial per workgroup
+    float *G = job.gpart;
+    {
+        float *g1 = G + ndp_off_Wi(&dd, 1), *g2 = G + ndp_off_Wi(&dd, 2);
+        const int col = 32 * wv + l31;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + mfma_row(r, h);
+                g1[row * NDP_W + col] = dW1[m][r];
+                g2[row * NDP_W + col] = dW2[m][r];
+            }
+    }
+    // column-wise accumulators: fold the two point-halves (ph = 0 then ph = 1) through LDS
+    float *sc = sm + L_BUFA;      // tiles are dead now
+    if (ph == 1) {
+        float *s = sc + o0 * 32;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) s[c] = gW0[c];
+        s[6] = gb0; s[7] = gb1; s[8] = gb2;
+#pragma unroll
+        for (int j = 0; j < NDP_NHMAX; ++j) s[9 + j] = gWh[j];
+    }
+    __syncthreads();
+    if (ph == 0) {
+        const float *s = sc + o0 * 32;
+        float *gw0 = G + ndp_off_W0(&dd), *gb0p = G + ndp_off_b0(&dd);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) gw0[o0 * 6 + c] = gW0[c] + s[c];
+        gb0p[o0] = gb0 + s[6];
+        G[ndp_off_bi(&dd, 1) + o0] = gb1 + s[7];
+        G[ndp_off_bi(&dd, 2) + o0] = gb2 + s[8];
+        float *gwh = G + ndp_off_Wi(&dd, 3);
+        for (int j = 0; j < hc.nh; ++j) gwh[j * NDP_W + o0] = gWh[j] + s[9 + j];
+        if (t < hc.nh) gwh[hc.nh * NDP_W + t] = gbh;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// standalone kernels
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(256)
+k_level_fwd(HeadCfg hc, LevelJob job) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    job.tile0 = blockIdx.x;
+    job.tile_step = gridDim.x;
+    level_fwd_body(hc, job, sm);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_level_bwd(HeadCfg hc, BwdJob job, int p_stride) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    job.tile0 = blockIdx.x;
+    job.tile_step = gridDim.x;
+    job.gpart += (size_t)blockIdx.x * p_stride;
+    level_bwd_body<false>(hc, job, sm);
+}
+
+extern "C" __global__ void k_grad_reduce(const float *gpart, int n_part, int p_stride, int P, float *grads) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float s = gpart[i];
+    for (int g = 1; g < n_part; ++g) s += gpart[(size_t)g * p_stride + i];
+    grads[i] = s;
+}
+
+// ---- brute-force 1-NN: one query per thread, references streamed through LDS in 1024-point chunks
+#define NN_CHUNK 1024
+__device__ __forceinline__ void nn_body(const float *q, int nq, const float *r, int nr, float *d2, int *idx,
+                                        int qbase, float *sm /*[NN_CHUNK][4]*/) {
+    const int t = threadIdx.x;
+    const int i = qbase + t;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (i < nq) { qx = q[3 * i]; qy = q[3 * i + 1]; qz = q[3 * i + 2]; }
+    float best = INFINITY;
+    int bi = -1;
+    for (int c0 = 0; c0 < nr; c0 += NN_CHUNK) {
+        const int cn = min(NN_CHUNK, nr - c0);
+        __syncthreads();
+        for (int j = t; j < cn; j += 256) {
+            const float *rp = r + 3 * (size_t)(c0 + j);
+            *reinterpret_cast<float4 *>(sm + 4 * j) = make_float4(rp[0], rp[1], rp[2], 0.f);
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int j = 0; j < cn; ++j) {
+            const float4 rv = *reinterpret_cast<const float4 *>(sm + 4 * j);
+            const float dx = qx - rv.x, dy = qy - rv.y, dz = qz - rv.z;
+            const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            if (dd < best) { best = dd; bi = c0 + j; }
+        }
+    }
+    if (i < nq) { d2[i] = best; idx[i] = bi; }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_nn(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y, int *idx_y) {
+    __shared__ __attribute__((aligned(16))) float sm[NN_CHUNK * 4];
+    const int bx = (S + 255) / 256;
+    if ((int)blockIdx.x < bx) nn_body(x, S, y, T, d2x, idx_x, blockIdx.x * 256, sm);
+    else nn_body(y, T, x, S, d2y, idx_y, (blockIdx.x - bx) * 256, sm);
+}
+
+// sum_i sqrt(d2_i) [d2_i < trunc], deterministic block reduction (all 256 threads get the value)
+__device__ __forceinline__ float l1_sum(const float *d2, int n, float trunc, float *scratch) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float v = d2[i];
+        s += (v >= trunc) ? 0.f : sqrtf(v);
+    }
+    return block_sum_256(s, scratch);
+}
+__device__ __forceinline__ float sq_sum(const float *x, const float *tt, int K, float *scratch) {
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float e0 = x[3 * k] - tt[3 * k], e1 = x[3 * k + 1] - tt[3 * k + 1], e2 = x[3 * k + 2] - tt[3 * k + 2];
+        s += fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
+    }
+    return block_sum_256(s, scratch);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_chamfer_bwd(const float *x, int S, const float *y, int T, float trunc, const float *d2x, const int *idx_x,
+              const float *d2y, const int *idx_y, float *loss, float *gx) {
+    __shared__ float scratch[256];
+    if (blockIdx.x == 0) {
+        const float sx = l1_sum(d2x, S, trunc, scratch);
+        const float sy = l1_sum(d2y, T, trunc, scratch);
+        if (threadIdx.x == 0) loss[0] = sx / (float)S + sy / (float)T;
+    }
+    if (!gx) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    const float xi[3] = {x[3 * i], x[3 * i + 1], x[3 * i + 2]};
+    float g[3] = {0.f, 0.f, 0.f};
+    if (!(d2x[i] >= trunc)) {
+        const float *yy = y + 3 * idx_x[i];
+        const float inv = 1.0f / ((float)S * sqrtf(d2x[i]));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[a] = (xi[a] - yy[a]) * inv;
+    }
+    for (int j = 0; j < T; ++j) {           // ascending j: same order as the oracle / the CPU reference
+        if (idx_y[j] == i && !(d2y[j] >= trunc)) {
+            const float inv = 1.0f / ((float)T * sqrtf(d2y[j]));
+#pragma unroll
+            for (int a = 0; a < 3; ++a) g[a] = fmaf(xi[a] - y[3 * j + a], inv, g[a]);
+        }
+    }
+    gx[3 * i] = g[0]; gx[3 * i + 1] = g[1]; gx[3 * i + 2] = g[2];
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_landmark(const float *x, const float *tt, int K, float *loss, float *gx) {
+    __shared__ float scratch[256];
+    const float invK = 1.0f / (float)K;
+    if (blockIdx.x == 0) {
+        const float s = sq_sum(x, tt, K, scratch);
+        if (threadIdx.x == 0) loss[0] = s * invK;
+    }
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < K && gx) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) gx[3 * k + a] = 2.0f * (x[3 * k + a] - tt[3 * k + a]) * invK;
+    }
+}
+
+// torch.optim.Adam single-tensor update, op for op (see oracle ndp_o_adam)
+__device__ __forceinline__ void adam_update(float &p, float g, float &m, float &v, float w1, float b2, float w2,
+                                            float neg_step, float bc2s, float eps) {
+    const float mi = m + w1 * (g - m);
+    float vi = v * b2;
+    vi = vi + (w2 * g) * g;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p = p + (neg_step * mi) / denom;
+    m = mi;
+    v = vi;
+}
+
+extern "C" __global__ void k_adam(float *p, const float *g, float *m, float *v, int P, float w1, float b2, float w2,
+                                  float neg_step, float bc2s, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float pi = p[i], mi = m[i], vi = v[i];
+    adam_update(pi, g[i], mi, vi, w1, b2, w2, neg_step, bc2s, eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched engine kernels: blockIdx.y = pair
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float level_freq(int level, int k0) { return ldexpf(1.0f, level + 1 + k0); }
+
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_fwd(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y;
+    const ndp_pair_state st = e.state[parity * e.B + b];
+    if (st.level >= e.m) return;
+    const ndp_pair_geom gm = e.geom[b];
+    LevelJob job;
+    job.n = gm.K + gm.S;
+    job.n_tiles = (job.n + NDP_TILE - 1) / NDP_TILE;
+    if ((int)blockIdx.x >= job.n_tiles) return;
+    const HeadCfg hc = make_head_cfg(e.desc);
+    job.params = e.params + ((size_t)b * e.m + st.level) * e.p_stride;
+    job.freq = level_freq(st.level, e.k0);
+    float *pts = e.pts + (size_t)b * 2 * e.n_cap * 3;
+    job.x_in = pts + (size_t)st.cur * e.n_cap * 3;
+    job.x_out = pts + (size_t)(st.cur ^ 1) * e.n_cap * 3;
+    job.act = e.act + (size_t)b * 3 * e.n_cap * NDP_W;
+    job.heads = e.heads + (size_t)b * e.n_cap * NDP_NHMAX;
+    job.plane = e.n_cap;
+    job.tile0 = blockIdx.x;
+    job.tile_step = gridDim.x;
+    level_fwd_body(hc, job, sm);
+}
+
+// blockIdx.x < n_cap/256: source samples -> targets;  else targets -> source samples
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_nn(ndp_engine e, int parity) {
+    __shared__ __attribute__((aligned(16))) float sm[NN_CHUNK * 4];
+    const int b = blockIdx.y;
+    const ndp_pair_state st = e.state[parity * e.B + b];
+    if (st.level >= e.m) return;
+    const ndp_pair_geom gm = e.geom[b];
+    if (gm.S == 0 || e.w_cd == 0.f) return;
+    const float *xw = e.pts + ((size_t)b * 2 + (st.cur ^ 1)) * e.n_cap * 3 + 3 * gm.K;
+    const float *y = e.tgt + (size_t)b * e.t_cap * 3;
+    const int bx = (e.n_cap + 255) / 256;
+    if ((int)blockIdx.x < bx) {
+        const int qb = blockIdx.x * 256;
+        if (qb >= gm.S) return;
+        nn_body(xw, gm.S, y, gm.T, e.d2x + (size_t)b * e.n_cap, e.idx_x + (size_t)b * e.n_cap, qb, sm);
+    } else {
+        const int qb = (blockIdx.x - bx) * 256;
+        float *d2y = e.d2y + (size_t)b * e.t_cap;
+        int *iy = e.idx_y + (size_t)b * e.t_cap;
+        if (qb >= gm.T) {                   // keep the -1 padding the match scan relies on
+            for (int j = qb + threadIdx.x; j < min(qb + 256, e.t_cap); j += 256) iy[j] = -1;
+            return;
+        }
+        nn_body(y, gm.T, xw, gm.S, d2y, iy, qb, sm);
+        const int j = qb + threadIdx.x;
+        if (j >= gm.T && j < e.t_cap) iy[j] = -1;
+    }
+}
+
+// loss -> early-stop decision (every workgroup recomputes it identically) -> backward of the live tiles
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_bwd(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y;
+    const ndp_pair_state st = e.state[parity * e.B + b];
+    ndp_pair_state *nst = e.state + (size_t)(parity ^ 1) * e.B + b;
+    if (st.level >= e.m) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) { ndp_pair_state c = st; c.decision = NDP_DEC_IDLE; *nst = c; }
+        return;
+    }
+    const ndp_pair_geom gm = e.geom[b];
+    const int n = gm.K + gm.S;
+    const float *pts = e.pts + (size_t)b * 2 * e.n_cap * 3;
+    const float *x_in = pts + (size_t)st.cur * e.n_cap * 3;
+    const float *x_out = pts + (size_t)(st.cur ^ 1) * e.n_cap * 3;
+    const float *ldmk_t = e.ldmk_t + (size_t)b * e.n_cap * 3;
+    const float *tgt = e.tgt + (size_t)b * e.t_cap * 3;
+    const float *d2x = e.d2x + (size_t)b * e.n_cap, *d2y = e.d2y + (size_t)b * e.t_cap;
+    const bool use_cd = gm.S > 0 && e.w_cd != 0.f;
+
+    // ---- loss (registration.py:193-212; loss.py:185-258)
+    float *red = sm + L_RED;
+    float loss = 0.f;
+    if (gm.K > 0) loss = sq_sum(x_out, ldmk_t, gm.K, red) * (1.0f / (float)gm.K);
+    if (use_cd) {
+        const float sx = l1_sum(d2x, gm.S, e.trunc, red);
+        const float sy = l1_sum(d2y, gm.T, e.trunc, red);
+        const float lcd = sx / (float)gm.S + sy / (float)gm.T;
+        loss = gm.K > 0 ? loss + e.w_cd * lcd : lcd;
+    }
+    // ---- early stop (registration.py:226-232), in double like the reference's Python floats
+    int bc = st.break_counter;
+    double lp = st.loss_prev;
+    bool stop = false;
+    if (e.early_stop) {
+        const double L = (double)loss;
+        if (L < 1e-4) stop = true;
+        else {
+            if (fabs(lp - L) < lp * e.break_threshold_ratio) bc += 1;
+            if (bc >= e.max_break_count) stop = true;
+            else lp = L;
+        }
+    }
+    const int decision = stop ? NDP_DEC_ADVANCE : (st.iter + 1 >= e.iters ? NDP_DEC_STEP_ADVANCE : NDP_DEC_STEP);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        ndp_pair_state c = st;
+        c.loss = loss;
+        c.decision = decision;
+        c.total_evals = st.total_evals + 1;
+        c.step_level = st.level;
+        c.step_t = st.adam_t + 1;
+        if (decision != NDP_DEC_ADVANCE) c.total_steps = st.total_steps + 1;
+        if (decision == NDP_DEC_STEP) {
+            c.iter = st.iter + 1;
+            c.adam_t = st.adam_t + 1;
+            c.break_counter = bc;
+            c.loss_prev = lp;
+        } else {                                       // registration.py:242-249 + :179-180
+            c.evals_per_level[st.level] = st.iter + 1;
+            c.level = st.level + 1;
+            c.iter = 0;
+            c.adam_t = 0;
+            c.break_counter = 0;
+            c.loss_prev = 1e6;
+            c.cur = st.cur ^ 1;
+        }
+        *nst = c;
+    }
+    if (decision == NDP_DEC_ADVANCE) return;
+    const int n_tiles = (n + NDP_TILE - 1) / NDP_TILE;
+    float *gpart = e.gpart + ((size_t)b * e.G + blockIdx.x) * e.p_stride;
+    if ((int)blockIdx.x >= n_tiles) {                  // no tile for this workgroup: its partial is zero
+        for (int i = threadIdx.x; i < e.P; i += 256) gpart[i] = 0.f;
+        return;
+    }
+    const HeadCfg hc = make_head_cfg(e.desc);
+    BwdJob job;
+    job.params = e.params + ((size_t)b * e.m + st.level) * e.p_stride;
+    job.freq = level_freq(st.level, e.k0);
+    job.x_in = x_in;
+    job.act = e.act + (size_t)b * 3 * e.n_cap * NDP_W;
+    job.heads = e.heads + (size_t)b * e.n_cap * NDP_NHMAX;
+    job.g = nullptr;
+    job.gpart = gpart;
+    job.n = n; job.plane = e.n_cap; job.n_tiles = n_tiles;
+    job.tile0 = blockIdx.x; job.tile_step = gridDim.x;
+    job.x_out = x_out; job.ldmk_t = ldmk_t; job.tgt = tgt;
+    job.d2x = d2x; job.idx_x = e.idx_x + (size_t)b * e.n_cap;
+    job.d2y = d2y; job.idx_y = e.idx_y + (size_t)b * e.t_cap;
+    job.K = gm.K; job.S = gm.S; job.T = gm.T; job.t_cap = e.t_cap;
+    job.w_cd = use_cd ? e.w_cd : 0.f; job.trunc = e.trunc;
+    level_bwd_body<true>(hc, job, sm);
+}
+
+// fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state)
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_update(ndp_engine e, int parity) {
+    const int b = blockIdx.y;
+    const ndp_pair_state ns = e.state[(size_t)(parity ^ 1) * e.B + b];      // written by k_eng_bwd this tick
+    if (ns.decision == NDP_DEC_IDLE) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= e.P) return;
+    float *m = e.adam_m + (size_t)b * e.p_stride, *v = e.adam_v + (size_t)b * e.p_stride;
+    if (ns.decision != NDP_DEC_ADVANCE) {
+        const float *gp = e.gpart + (size_t)b * e.G * e.p_stride;
+        float g = gp[i];
+        for (int k = 1; k < e.G; ++k) g += gp[(size_t)k * e.p_stride + i];
+        float *p = e.params + ((size_t)b * e.m + ns.step_level) * e.p_stride;
+        float pi = p[i], mi = m[i], vi = v[i];
+        adam_update(pi, g, mi, vi, e.adam_w1, e.adam_b2, e.adam_w2, e.adam_tab[2 * ns.step_t],
+                    e.adam_tab[2 * ns.step_t + 1], e.adam_eps);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+    if (ns.decision != NDP_DEC_STEP) { m[i] = 0.f; v[i] = 0.f; }             // registration.py:176
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side of the C ABI
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[256] = "";
+static int fail(int code, const char *msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return code;
+}
+static int hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof g_err, "%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+#define HIP_TRY(expr, what)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return hip_fail(_e, what);      \
+    } while (0)
+
+static int check_desc(const ndp_layer_desc *d) {
+    if (!d) return fail(NDP_E_INVALID, "null layer descriptor");
+    if (d->width != NDP_W || d->n_hidden != 2)
+        return fail(NDP_E_UNSUPPORTED, "kernels are specialised for width=128, depth=3");
+    if (d->nonrigidity) return fail(NDP_E_UNSUPPORTED, "nonrigidity gate (w_reg > 0) not implemented in the HIP path yet");
+    if (d->motion < 0 || d->motion > 2) return fail(NDP_E_INVALID, "bad motion type");
+    if (d->motion != NDP_MOTION_SFLOW && d->rotfmt != NDP_ROT_AXIS_ANGLE && d->rotfmt != NDP_ROT_EULER)
+        return fail(NDP_E_UNSUPPORTED, "rotation_format must be axis_angle or euler in the HIP path");
+    return 0;
+}
+static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+static int set_smem(const void *fn) {
+    static thread_local const void *done[8];
+    for (auto d : done) if (d == fn) return 0;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes), "hipFuncSetAttribute");
+    for (auto &d : done) if (!d) { d = fn; break; }
+    return 0;
+}
+
+extern "C" int ndp_version(void) { return 100; }
+extern "C" const char *ndp_last_error(void) { return g_err; }
+
+extern "C" int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
+                             const float *x, int n, float *x_out, float *act, float *heads, void *stream) {
+    if (int rc = check_desc(desc)) return rc;
+    if (n < 0 || !params || (n > 0 && (!x || !x_out))) return fail(NDP_E_INVALID, "ndp_level_fwd: null pointer / negative n");
+    if (!aligned16(params) || (act && !aligned16(act)) || (heads && !aligned16(heads)))
+        return fail(NDP_E_INVALID, "ndp_level_fwd: params/act/heads must be 16-byte aligned");
+    if (n == 0) return 0;
+    LevelJob job;
+    job.params = params; job.freq = ldexpf(1.0f, level + 1 + k0);
+    job.x_in = x; job.x_out = x_out; job.act = act; job.heads = heads;
+    job.n = n; job.n_tiles = (n + NDP_TILE - 1) / NDP_TILE; job.plane = job.n_tiles * NDP_TILE;
+    job.tile0 = 0; job.tile_step = 0;
+    if (int rc = set_smem((const void *)k_level_fwd)) return rc;
+    const int grid = job.n_tiles < 1024 ? job.n_tiles : 1024;
+    hipLaunchKernelGGL(k_level_fwd, dim3(grid), dim3(256), kSmemBytes, (hipStream_t)stream, make_head_cfg(*desc), job);
+    HIP_TRY(hipGetLastError(), "k_level_fwd launch");
+    return 0;
+}
+
+extern "C" int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
+                             const float *x, int n, const float *act, const float *heads, const float *g,
+                             float *grads_part, int n_part, int p_stride, void *stream) {
+    if (int rc = check_desc(desc)) return rc;
+    if (n <= 0 || !params || !x || !act || !heads || !g || !grads_part || n_part < 1)
+        return fail(NDP_E_INVALID, "ndp_level_bwd: null pointer / bad sizes");
+    if (p_stride < ndp_param_count(desc)) return fail(NDP_E_INVALID, "ndp_level_bwd: p_stride < P");
+    if (!aligned16(params) || !aligned16(act) || !aligned16(heads))
+        return fail(NDP_E_INVALID, "ndp_level_bwd: params/act/heads must be 16-byte aligned");
+    BwdJob job;
+    memset(&job, 0, sizeof job);
+    job.params = params; job.freq = ldexpf(1.0f, level + 1 + k0);
+    job.x_in = x; job.act = act; job.heads = heads; job.g = g; job.gpart = grads_part;
+    job.n = n; job.n_tiles = (n + NDP_TILE - 1) / NDP_TILE; job.plane = job.n_tiles * NDP_TILE;
+    if (n_part > job.n_tiles) {
+        // partials with no tile must read as zero
+        HIP_TRY(hipMemsetAsync(grads_part + (size_t)job.n_tiles * p_stride, 0,
+                               sizeof(float) * (size_t)(n_part - job.n_tiles) * p_stride, (hipStream_t)stream), "memset");
+        n_part = job.n_tiles;
+    }
+    if (int rc = set_smem((const void *)k_level_bwd)) return rc;
+    hipLaunchKernelGGL(k_level_bwd, dim3(n_part), dim3(256), kSmemBytes, (hipStream_t)stream, make_head_cfg(*desc), job, p_stride);
+    HIP_TRY(hipGetLastError(), "k_level_bwd launch");
+    return 0;
+}
+
+extern "C" int ndp_grad_reduce(const float *grads_part, int n_part, int p_stride, int P, float *grads, void *stream) {
+    if (!grads_part || !grads || n_part < 1 || P < 1) return fail(NDP_E_INVALID, "ndp_grad_reduce: bad arguments");
+    hipLaunchKernelGGL(k_grad_reduce, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, grads_part, n_part, p_stride, P, grads);
+    HIP_TRY(hipGetLastError(), "k_grad_reduce launch");
+    return 0;
+}
+
+extern "C" int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const float *params_all, int p_stride,
+                               const float *x, int n, float *x_out, float *tmp, void *stream) {
+    if (int rc = check_desc(desc)) return rc;
+    if (m < 0 || m > NDP_MAX_LEVELS || n < 0 || !x_out || (m > 1 && !tmp)) return fail(NDP_E_INVALID, "ndp_pyramid_fwd: bad arguments");
+    if (n == 0) return 0;
+    if (m == 0) {
+        HIP_TRY(hipMemcpyAsync(x_out, x, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream), "memcpy");
+        return 0;
+    }
+    // ping-pong so that the last level lands in x_out
+    const float *src = x;
+    for (int l = 0; l < m; ++l) {
+        float *dst = ((m - 1 - l) % 2 == 0) ? x_out : tmp;
+        if (int rc = ndp_level_fwd(desc, params_all + (size_t)l * p_stride, l, k0, src, n, dst, nullptr, nullptr, stream)) return rc;
+        src = dst;
+    }
+    return 0;
+}
+
+extern "C" int ndp_chamfer_nn_fwd(const float *x, int S, const float *y, int T,
+                                  float *d2x, int *idx_x, float *d2y, int *idx_y, void *stream) {
+    if (S <= 0 || T <= 0 || !x || !y || !d2x || !idx_x || !d2y || !idx_y) return fail(NDP_E_INVALID, "ndp_chamfer_nn_fwd: bad arguments");
+    const int grid = (S + 255) / 256 + (T + 255) / 256;
+    hipLaunchKernelGGL(k_nn, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, S, y, T, d2x, idx_x, d2y, idx_y);
+    HIP_TRY(hipGetLastError(), "k_nn launch");
+    return 0;
+}
+
+extern "C" int ndp_chamfer_l1_bwd(const float *x, int S, const float *y, int T, float trunc,
+                                  const float *d2x, const int *idx_x, const float *d2y, const int *idx_y,
+                                  float *loss, float *gx, void *stream) {
+    if (S <= 0 || T <= 0 || !x || !y || !d2x || !idx_x || !d2y || !idx_y || !loss) return fail(NDP_E_INVALID, "ndp_chamfer_l1_bwd: bad arguments");
+    hipLaunchKernelGGL(k_chamfer_bwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, S, y, T, trunc, d2x, idx_x, d2y, idx_y, loss, gx);
+    HIP_TRY(hipGetLastError(), "k_chamfer_bwd launch");
+    return 0;
+}
+
+extern "C" int ndp_landmark_mse_fwd_bwd(const float *x, const float *t, int K, float *loss, float *gx, void *stream) {
+    if (K <= 0 || !x || !t || !loss) return fail(NDP_E_INVALID, "ndp_landmark_mse_fwd_bwd: bad arguments");
+    hipLaunchKernelGGL(k_landmark, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, t, K, loss, gx);
+    HIP_TRY(hipGetLastError(), "k_landmark launch");
+    return 0;
+}
+
+extern "C" int ndp_adam_step(float *params, const float *grads, float *m, float *v, int P,
+                             float w1, float b2, float w2, float neg_step, float bc2_sqrt, float eps, void *stream) {
+    if (P <= 0 || !params || !grads || !m || !v) return fail(NDP_E_INVALID, "ndp_adam_step: bad arguments");
+    hipLaunchKernelGGL(k_adam, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, params, grads, m, v, P, w1, b2, w2, neg_step, bc2_sqrt, eps);
+    HIP_TRY(hipGetLastError(), "k_adam launch");
+    return 0;
+}
+
+extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream) {
+    if (!e) return fail(NDP_E_INVALID, "null engine");
+    if (int rc = check_desc(&e->desc)) return rc;
+    if (e->B < 1 || e->G < 1 || e->m < 1 || e->m > NDP_MAX_LEVELS || e->n_cap % NDP_TILE || e->t_cap % NDP_TILE ||
+        e->P != ndp_param_count(&e->desc) || e->p_stride < e->P || (e->p_stride & 3))
+        return fail(NDP_E_INVALID, "ndp_engine_run: inconsistent engine descriptor");
+    if (!e->geom || !e->state || !e->pts || !e->params || !e->gpart || !e->adam_m || !e->adam_v || !e->act ||
+        !e->heads || !e->adam_tab)
+        return fail(NDP_E_INVALID, "ndp_engine_run: null buffer");
+    if (int rc = set_smem((const void *)k_eng_fwd)) return rc;
+    if (int rc = set_smem((const void *)k_eng_bwd)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 blk(256);
+    const dim3 g_lvl(e->G, e->B);
+    const dim3 g_nn((e->n_cap + 255) / 256 + (e->t_cap + 255) / 256, e->B);
+    const dim3 g_upd((e->P + 255) / 256, e->B);
+    for (int k = 0; k < n_ticks; ++k) {
+        const int parity = (tick0 + k) & 1;
+        hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemBytes, s, *e, parity);
+        if (e->w_cd != 0.f && e->d2x) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_bwd, g_lvl, blk, kSmemBytes, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+    }
+    HIP_TRY(hipGetLastError(), "engine launch");
+    return 0;
+}

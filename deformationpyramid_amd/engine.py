@@ -1,0 +1,149 @@
+"""Batched NDP optimisation engine -- host plumbing around ndp_engine_run().
+
+B independent pairs are resident in HBM at once ("slots").  One *tick* is one iteration of the
+inner loop of optimize_deformation_pyramid (/root/reference/model/registration.py:184-238) for
+every unfinished slot: level forward -> 1-NN in both directions -> loss + early-stop decision +
+backward -> gradient fold + Adam (+ level hand-over).  Each slot is at its own level/iteration;
+the decision is taken on the device, the host only polls the slot states every few ticks.
+
+Memory per slot (n_cap = t_cap = 2048, m = 9): params 1.25 MB, activations 3 MB, Adam 0.28 MB,
+gradient partials G x 0.14 MB -- hundreds of slots fit easily in 288 GB of HBM3E.
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .layout import LayerDesc
+from .ops import adam_scalars, cap
+
+
+@dataclass
+class OptConfig:
+    m: int = 9
+    k0: int = -8
+    iters: int = 500
+    lr: float = 0.01
+    max_break_count: int = 15
+    break_threshold_ratio: float = 0.001
+    w_cd: float = 1.0          # weight of the Chamfer term (1 without landmarks; config.w_cd with)
+    trunc: float = 1e9         # truncation in squared units (registration.py:212 / config.trunc_cd)
+    early_stop: bool = True
+
+
+class BatchedEngine:
+    def __init__(self, desc: LayerDesc, cfg: OptConfig, B: int, n_cap: int, t_cap: int, device, G=None):
+        if desc.nonrigidity:
+            raise N.NdpError("nonrigidity gate (w_reg > 0) is not implemented in the HIP path")
+        self.lib = N.lib()
+        self.desc, self.cfg, self.B = desc, cfg, B
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise N.NdpError("BatchedEngine needs a GPU device; there is no CPU fallback")
+        self.n_cap, self.t_cap = cap(n_cap), cap(t_cap)
+        self.P = desc.param_count
+        self.p_stride = (self.P + 63) // 64 * 64
+        tiles = self.n_cap // N.TILE
+        self.G = int(G) if G else max(1, min(tiles, -(-512 // B)))
+        d = self.device
+        f32 = dict(device=d, dtype=torch.float32)
+        m = cfg.m
+        self.pts = torch.zeros(B, 2, self.n_cap, 3, **f32)
+        self.ldmk_t = torch.zeros(B, self.n_cap, 3, **f32)
+        self.tgt = torch.zeros(B, self.t_cap, 3, **f32)
+        self.params = torch.zeros(B, m, self.p_stride, **f32)
+        self.gpart = torch.zeros(B, self.G, self.p_stride, **f32)
+        self.adam_m = torch.zeros(B, self.p_stride, **f32)
+        self.adam_v = torch.zeros(B, self.p_stride, **f32)
+        self.act = torch.zeros(B, 3, self.n_cap, 128, **f32)
+        self.heads = torch.zeros(B, self.n_cap, N.NHMAX, **f32)
+        self.d2x = torch.zeros(B, self.n_cap, **f32)
+        self.d2y = torch.zeros(B, self.t_cap, **f32)
+        self.idx_x = torch.zeros(B, self.n_cap, device=d, dtype=torch.int32)
+        self.idx_y = torch.full((B, self.t_cap), -1, device=d, dtype=torch.int32)
+        tab = np.zeros((cfg.iters + 1, 2), dtype=np.float32)
+        for t in range(1, cfg.iters + 1):
+            tab[t] = adam_scalars(t, cfg.lr)
+        self.adam_tab = torch.from_numpy(tab).to(d)
+        self.state_nbytes = ctypes.sizeof(N.PairState)
+        self.state = torch.zeros(2, B, self.state_nbytes, device=d, dtype=torch.uint8)
+        self.geom = torch.zeros(B, 4, device=d, dtype=torch.int32)
+        self._geom_h = np.zeros((B, 4), dtype=np.int32)
+        self._state_h = torch.zeros(B, self.state_nbytes, dtype=torch.uint8).pin_memory()
+        self.tick = 0
+        self._mk_struct()
+
+    def _mk_struct(self):
+        c, e = self.cfg, N.Engine()
+        e.desc = self.desc.c_struct()
+        e.m, e.k0, e.P, e.p_stride = c.m, c.k0, self.P, self.p_stride
+        e.iters, e.max_break_count, e.early_stop = c.iters, c.max_break_count, int(bool(c.early_stop))
+        e.B, e.G, e.n_cap, e.t_cap = self.B, self.G, self.n_cap, self.t_cap
+        e.break_threshold_ratio = c.break_threshold_ratio
+        e.w_cd, e.trunc = c.w_cd, c.trunc
+        e.adam_w1, e.adam_b2, e.adam_w2, e.adam_eps = 1 - 0.9, 0.999, 1 - 0.999, 1e-8
+        for name in ("geom", "state", "pts", "ldmk_t", "tgt", "params", "gpart", "adam_m", "adam_v", "act", "heads",
+                     "d2x", "idx_x", "d2y", "idx_y", "adam_tab"):
+            setattr(e, name, getattr(self, name).data_ptr())
+        self.c_engine = e
+
+    # ------------------------------------------------------------------ slot management
+    def load(self, slot, pts, K, S, ldmk_t, tgt, params):
+        """pts [K+S,3] centred source points (landmarks first); ldmk_t [K,3]; tgt [T,3];
+        params [m, >=P] initial parameters of every level.  All tensors may live on any device."""
+        n = K + S
+        T = 0 if tgt is None else tgt.shape[0]
+        if n > self.n_cap or T > self.t_cap or n < 1:
+            raise ValueError(f"pair does not fit the engine capacities: n={n}/{self.n_cap}, T={T}/{self.t_cap}")
+        self.pts[slot].zero_()
+        self.pts[slot, 0, :n] = pts.to(self.device, torch.float32)
+        if K:
+            self.ldmk_t[slot, :K] = ldmk_t.to(self.device, torch.float32)
+        if T:
+            self.tgt[slot, :T] = tgt.to(self.device, torch.float32)
+        self.params[slot, :, :self.P] = params[:, :self.P].to(self.device, torch.float32)
+        self.adam_m[slot].zero_()
+        self.adam_v[slot].zero_()
+        self._geom_h[slot] = (K, S, T, 0)
+        self.geom[slot] = torch.from_numpy(self._geom_h[slot]).to(self.device)
+        st = N.PairState()
+        st.loss_prev = 1e6
+        buf = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
+        self.state[self.tick & 1, slot] = buf
+
+    def park(self, slot):
+        """Mark a slot as finished (empty)."""
+        st = N.PairState()
+        st.level = self.cfg.m
+        buf = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
+        self.state[self.tick & 1, slot] = buf
+
+    def run_ticks(self, n_ticks):
+        N.check(self.lib.ndp_engine_run(ctypes.byref(self.c_engine), self.tick, int(n_ticks),
+                                        N.stream_ptr(self.device)), "ndp_engine_run")
+        self.tick += n_ticks
+
+    def read_states(self):
+        self._state_h.copy_(self.state[self.tick & 1], non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        raw = self._state_h.numpy().tobytes()
+        sz = self.state_nbytes
+        return [N.PairState.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(self.B)]
+
+    def run_until_done(self, chunk=32, max_ticks=None):
+        """Advance every loaded slot to the end of its last level; returns the slot states."""
+        limit = max_ticks if max_ticks is not None else self.cfg.m * (self.cfg.iters + 1) + chunk
+        done_ticks = 0
+        while True:
+            self.run_ticks(chunk)
+            done_ticks += chunk
+            st = self.read_states()
+            if all(s.level >= self.cfg.m for s in st) or done_ticks >= limit:
+                return st
+
+    def final_points(self, slot, state):
+        """Points of a slot warped through every optimised level (what the next level would read)."""
+        g = self._geom_h[slot]
+        return self.pts[slot, state.cur, :g[0] + g[1]]

@@ -101,8 +101,9 @@ class Deformation_Pyramid:
             for i in range(m)
         ]
         self.pmax = max(d.param_count for d in self.descs) if m else 0
+        self.p_stride = (self.pmax + 63) // 64 * 64          # rows stay 16-byte aligned for the kernels
         # all levels are initialised on the CPU generator first (nets.py:20-30), then moved
-        store = torch.zeros(m, self.pmax, dtype=torch.float32)
+        store = torch.zeros(m, self.p_stride, dtype=torch.float32)
         for i, d in enumerate(self.descs):
             store[i, :d.param_count] = _init_level_flat(d, depth)
         self.store = store.to(self.device)

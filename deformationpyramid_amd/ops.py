@@ -1,0 +1,186 @@
+"""torch-tensor wrappers around the single-pair operators of libndp_hip.so.
+
+Torch is plumbing here: it owns device memory and the stream; all arithmetic is in the HIP
+library.  Every function requires CUDA(HIP) float32 contiguous tensors and raises otherwise --
+there is no CPU / eager fallback.
+"""
+import ctypes
+import math
+
+import torch
+
+from . import _native as N
+from .layout import LayerDesc
+
+TILE = N.TILE
+
+
+def _chk(t, name, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise N.NdpError(f"{name}: the HIP path needs a tensor on the GPU (got {getattr(t, 'device', type(t))}); "
+                         "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise N.NdpError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise N.NdpError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def cap(n):
+    return max(TILE, (n + TILE - 1) // TILE * TILE)
+
+
+def level_fwd(desc: LayerDesc, params, level, k0, x, save=False):
+    """x [n,3] -> x_out [n,3] (+ (act [3,cap,128], heads [cap,16]) when save)."""
+    _chk(params, "params"); _chk(x, "x")
+    n = x.shape[0]
+    out = torch.empty_like(x)
+    act = heads = None
+    if save:
+        c = cap(n)
+        act = torch.empty(3, c, 128, device=x.device, dtype=torch.float32)
+        heads = torch.empty(c, N.NHMAX, device=x.device, dtype=torch.float32)
+    cd = desc.c_struct()
+    N.check(N.lib().ndp_level_fwd(ctypes.byref(cd), _p(params), int(level), int(k0), _p(x), n, _p(out),
+                                  _p(act), _p(heads), N.stream_ptr(x.device)), "ndp_level_fwd")
+    return (out, act, heads) if save else out
+
+
+def level_bwd(desc: LayerDesc, params, level, k0, x, act, heads, g, n_part=None):
+    """-> grads [P] (partials folded in index order on the device)."""
+    _chk(params, "params"); _chk(x, "x"); _chk(act, "act"); _chk(heads, "heads"); _chk(g, "g")
+    n = x.shape[0]
+    P = desc.param_count
+    stride = (P + 3) // 4 * 4
+    tiles = (n + TILE - 1) // TILE
+    if n_part is None:
+        n_part = min(tiles, 256)
+    part = torch.empty(n_part, stride, device=x.device, dtype=torch.float32)
+    cd = desc.c_struct()
+    st = N.stream_ptr(x.device)
+    N.check(N.lib().ndp_level_bwd(ctypes.byref(cd), _p(params), int(level), int(k0), _p(x), n, _p(act), _p(heads),
+                                  _p(g), _p(part), n_part, stride, st), "ndp_level_bwd")
+    grads = torch.empty(P, device=x.device, dtype=torch.float32)
+    N.check(N.lib().ndp_grad_reduce(_p(part), n_part, stride, P, _p(grads), st), "ndp_grad_reduce")
+    return grads
+
+
+def pyramid_fwd(desc: LayerDesc, m, k0, store, x):
+    """store [m, p_stride] (level l in row l) ; x [n,3] -> [n,3]."""
+    _chk(store, "store"); _chk(x, "x")
+    out = torch.empty_like(x)
+    tmp = torch.empty_like(x)
+    cd = desc.c_struct()
+    N.check(N.lib().ndp_pyramid_fwd(ctypes.byref(cd), int(m), int(k0), _p(store), store.stride(0), _p(x), x.shape[0],
+                                    _p(out), _p(tmp), N.stream_ptr(x.device)), "ndp_pyramid_fwd")
+    return out
+
+
+def chamfer_nn(x, y):
+    _chk(x, "x"); _chk(y, "y")
+    S, T = x.shape[0], y.shape[0]
+    d2x = torch.empty(S, device=x.device); d2y = torch.empty(T, device=x.device)
+    ix = torch.empty(S, device=x.device, dtype=torch.int32); iy = torch.empty(T, device=x.device, dtype=torch.int32)
+    N.check(N.lib().ndp_chamfer_nn_fwd(_p(x), S, _p(y), T, _p(d2x), _p(ix), _p(d2y), _p(iy), N.stream_ptr(x.device)),
+            "ndp_chamfer_nn_fwd")
+    return d2x, ix, d2y, iy
+
+
+def chamfer_l1(x, y, trunc, nn=None, want_grad=True):
+    """-> (loss [1], gx [S,3] | None, nn tuple)."""
+    if nn is None:
+        nn = chamfer_nn(x, y)
+    d2x, ix, d2y, iy = nn
+    loss = torch.empty(1, device=x.device)
+    gx = torch.empty_like(x) if want_grad else None
+    N.check(N.lib().ndp_chamfer_l1_bwd(_p(x), x.shape[0], _p(y), y.shape[0], float(trunc), _p(d2x), _p(ix), _p(d2y),
+                                       _p(iy), _p(loss), _p(gx), N.stream_ptr(x.device)), "ndp_chamfer_l1_bwd")
+    return loss, gx, nn
+
+
+def landmark_mse(x, t):
+    _chk(x, "x"); _chk(t, "t")
+    loss = torch.empty(1, device=x.device)
+    gx = torch.empty_like(x)
+    N.check(N.lib().ndp_landmark_mse_fwd_bwd(_p(x), _p(t), x.shape[0], _p(loss), _p(gx), N.stream_ptr(x.device)),
+            "ndp_landmark_mse_fwd_bwd")
+    return loss, gx
+
+
+def adam_scalars(t, lr=0.01, b1=0.9, b2=0.999):
+    """(neg_step, bc2_sqrt) of torch.optim.Adam's single-tensor path, computed in Python doubles."""
+    bc1 = 1 - b1 ** t
+    bc2 = 1 - b2 ** t
+    return -(lr / bc1), math.sqrt(bc2)
+
+
+def adam_step(p, g, m, v, t, lr=0.01, b1=0.9, b2=0.999, eps=1e-8):
+    for a, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(a, nm)
+    ns, bc2s = adam_scalars(t, lr, b1, b2)
+    N.check(N.lib().ndp_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), 1 - b1, b2, 1 - b2, ns, bc2s, eps,
+                                  N.stream_ptr(p.device)), "ndp_adam_step")
+
+
+# ------------------------------------------------------------------------------ autograd wrappers
+class _LevelWarpFn(torch.autograd.Function):
+    """NDPLayer.forward (nets.py:111-140) for callers that own their optimisation loop
+    (shape_transfer.py:116-157).  x is treated as detached, as on the reference's hot path."""
+
+    @staticmethod
+    def forward(ctx, x, layer, *params):
+        need = any(p.requires_grad for p in params)
+        flat = layer.flat.detach()
+        if need:
+            out, act, heads = level_fwd(layer.desc, flat, layer.level, layer.k0, x.detach().contiguous(), save=True)
+            ctx.save_for_backward(x.detach().contiguous(), act, heads)
+            ctx.layer = layer
+        else:
+            out = level_fwd(layer.desc, flat, layer.level, layer.k0, x.detach().contiguous())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, act, heads = ctx.saved_tensors
+        layer = ctx.layer
+        grads = level_bwd(layer.desc, layer.flat.detach(), layer.level, layer.k0, x, act, heads, g.contiguous())
+        outs = []
+        for name, off, shape in layer.desc.named_slices():
+            n = 1
+            for s in shape:
+                n *= s
+            outs.append(grads[off:off + n].view(shape))
+        return (None, None) + tuple(outs)
+
+
+def level_warp(layer, x):
+    """-> (x', nonrigidity=None).  Squeeze semantics of nets.py:140 are not reproduced (n >= 2)."""
+    if layer.desc.nonrigidity:
+        raise N.NdpError("nonrigidity gate (w_reg > 0) is not implemented in the HIP path")
+    if x.dim() != 2 or x.shape[-1] != 3:
+        raise ValueError("expected points of shape [n, 3]")
+    params = tuple(layer.parameters())
+    return _LevelWarpFn.apply(x.float(), layer, *params), None
+
+
+class _ChamferFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y, trunc):
+        xd, yd = x.detach().contiguous(), y.detach().contiguous()
+        loss, gx, _ = chamfer_l1(xd, yd, trunc, want_grad=x.requires_grad)
+        ctx.save_for_backward(gx if gx is not None else torch.empty(0, device=x.device))
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (gx,) = ctx.saved_tensors
+        return (gx * g if gx.numel() else None), None, None
+
+
+def chamfer_distance(x, y, trunc):
+    """Differentiable (wrt x) truncated L1 Chamfer of two [n,3] clouds."""
+    return _ChamferFn.apply(x, y, float(trunc))

@@ -1,0 +1,146 @@
+/*
+ * ndp_hip.h -- C ABI of libndp_hip.so, the MI355X (gfx950) implementation of the NDP per-pair
+ * optimisation hot path.  Plain pointers and sizes only: every `float*`/`int*` below is a DEVICE
+ * pointer to contiguous memory owned by the caller, `stream` is a hipStream_t passed as void*,
+ * nothing is allocated inside, there is no global state, and every entry point returns
+ *     0  success,   <0  invalid argument (NDP_E_*),   >0  a hipError_t from the launch.
+ *
+ * The reference has no C ABI: its "operator API" for this path is the Python surface of
+ * model/registration.py, model/nets.py and model/loss.py.  Each entry point names the reference
+ * code it replaces; INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Parameter layout of one level: include/ndp_types.h.  Points are float32 [n][3] row-major.
+ * The kernels are specialised for width = 128, depth = 3 (both shipped configs: NDP.yaml:24-25,
+ * LNDP.yaml:45-46); other shapes return NDP_E_UNSUPPORTED.
+ */
+#ifndef NDP_HIP_H
+#define NDP_HIP_H
+
+#include "ndp_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NDP_E_INVALID     (-1)
+#define NDP_E_UNSUPPORTED (-2)
+#define NDP_MAX_LEVELS    16
+#define NDP_TILE          64      /* points per tile; point capacities are multiples of this */
+
+int ndp_version(void);                 /* 100*major + minor */
+const char *ndp_last_error(void);      /* text of the last non-zero return on this thread */
+
+/* ------------------------------------------------------------------ single-pair operators */
+
+/* NDPLayer.forward for one level on n points (nets.py:111-140; posenc :164-177; MLP :295-304;
+ * get_Rotation :144-161; rigid_body.py:19-56,89-119).
+ *   x [n][3] -> x_out [n][3].
+ *   act  (may be NULL): [3][n_cap][128] saved post-ReLU activations h0,h1,h2 for ndp_level_bwd
+ *   heads(may be NULL): [n_cap][16] scaled head outputs (rot.., scale, trn, nr)
+ * n_cap = n rounded up to NDP_TILE (row count of act/heads).                                   */
+int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
+                  const float *x, int n, float *x_out, float *act, float *heads, void *stream);
+
+/* Backward of one level wrt its parameters given g = dL/dx_out [n][3] (autograd of nets.py:111-140;
+ * x is a detached input, registration.py:243-249).  act/heads come from ndp_level_fwd on the same
+ * x and params.  grads_part [n_part][P_stride] receives n_part partial sums (deterministic: block
+ * g sums tiles g, g+n_part, ...); ndp_grad_reduce or ndp_adam_step folds them in index order.   */
+int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
+                  const float *x, int n, const float *act, const float *heads, const float *g,
+                  float *grads_part, int n_part, int p_stride, void *stream);
+
+/* grads[P] = sum_{g<n_part} grads_part[g][:]  (fixed order). */
+int ndp_grad_reduce(const float *grads_part, int n_part, int p_stride, int P, float *grads, void *stream);
+
+/* Whole pyramid forward, levels 0..m-1 (Deformation_Pyramid.warp, nets.py:36-48; the final
+ * inference warp of registration.py:254-255).  params_all: level l at params_all + l*p_stride.
+ * tmp [n][3] scratch.                                                                           */
+int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const float *params_all, int p_stride,
+                    const float *x, int n, float *x_out, float *tmp, void *stream);
+
+/* Exact brute-force 1-NN in both directions (pytorch3d knn_points K=1 as called at loss.py:177-178):
+ * d2x[i] = min_j |x_i - y_j|^2 (fma chain over x,y,z), idx_x[i] = lowest argmin; same for y->x.  */
+int ndp_chamfer_nn_fwd(const float *x, int S, const float *y, int T,
+                       float *d2x, int *idx_x, float *d2y, int *idx_y, void *stream);
+
+/* Truncated L1 Chamfer value and gradient from the NN result (loss.py:185-258 and its autograd):
+ * loss[0] = sum_i sqrt(d2x_i)[d2x_i<trunc]/S + sum_j sqrt(d2y_j)[d2y_j<trunc]/T ;
+ * gx [S][3] = dloss/dx (contributions of y_j -> x_i added in ascending j).                      */
+int ndp_chamfer_l1_bwd(const float *x, int S, const float *y, int T, float trunc,
+                       const float *d2x, const int *idx_x, const float *d2y, const int *idx_y,
+                       float *loss, float *gx, void *stream);
+
+/* Landmark loss mean_k |x_k - t_k|^2 and gradient (registration.py:201-203). */
+int ndp_landmark_mse_fwd_bwd(const float *x, const float *t, int K, float *loss, float *gx, void *stream);
+
+/* torch.optim.Adam single-tensor step t (1-based) on P parameters (registration.py:176,237).
+ * neg_step = -(lr / (1 - b1^t)), bc2_sqrt = sqrt(1 - b2^t) are computed by the caller in double
+ * and passed as float, exactly as torch casts its Python scalars.                               */
+int ndp_adam_step(float *params, const float *grads, float *m, float *v, int P,
+                  float w1, float b2, float w2, float neg_step, float bc2_sqrt, float eps, void *stream);
+
+/* ------------------------------------------------------------------ batched engine
+ * B independent pairs advance together, one "tick" = one iteration of the inner loop of
+ * optimize_deformation_pyramid (registration.py:184-238) for every unfinished pair, each pair at
+ * its own level / iteration, early stop decided on the device (registration.py:226-232).        */
+
+typedef struct ndp_pair_geom {
+    int K;            /* landmark count (0 without landmarks)                        */
+    int S;            /* Chamfer source samples (0 in landmark-only mode)            */
+    int T;            /* Chamfer target samples                                      */
+    int pad;
+} ndp_pair_geom;
+
+typedef struct ndp_pair_state {
+    int level;                       /* current level; == m when the pair is finished           */
+    int iter;                        /* loss evaluations done at this level                     */
+    int break_counter;               /* registration.py:179                                     */
+    int adam_t;                      /* Adam steps taken at this level                          */
+    int cur;                         /* which half of pts[] is the level input                  */
+    int decision;                    /* what this tick's update kernel must do (NDP_DEC_*)      */
+    int total_steps;                 /* Adam steps over all levels                              */
+    int total_evals;                 /* loss evaluations over all levels                        */
+    float loss;                      /* last evaluated loss                                     */
+    int step_level;                  /* level this tick's Adam step applies to                  */
+    int step_t;                      /* Adam step number (1-based) of this tick's step          */
+    int pad;
+    double loss_prev;                /* registration.py:180                                     */
+    int evals_per_level[NDP_MAX_LEVELS];
+} ndp_pair_state;
+
+enum { NDP_DEC_STEP = 0, NDP_DEC_ADVANCE = 1, NDP_DEC_STEP_ADVANCE = 2, NDP_DEC_IDLE = 3 };
+
+typedef struct ndp_engine {
+    ndp_layer_desc desc;             /* shared by all levels (nonrigidity unsupported here)     */
+    int m, k0;
+    int P, p_stride;                 /* params per level, padded stride (multiple of 4)         */
+    int iters, max_break_count, early_stop;
+    int B, G;                        /* pairs; blocks per pair in the level kernels             */
+    int n_cap, t_cap;                /* per-pair capacities, multiples of NDP_TILE              */
+    double break_threshold_ratio;
+    float w_cd, trunc;
+    float adam_w1, adam_b2, adam_w2, adam_eps;
+    const ndp_pair_geom *geom;       /* [B]                                                     */
+    ndp_pair_state *state;           /* [2][B] double-buffered by tick parity                   */
+    float *pts;                      /* [B][2][n_cap][3]  landmarks first, then samples         */
+    const float *ldmk_t;             /* [B][n_cap][3]                                           */
+    const float *tgt;                /* [B][t_cap][3]                                           */
+    float *params;                   /* [B][m][p_stride]                                        */
+    float *gpart;                    /* [B][G][p_stride]                                        */
+    float *adam_m, *adam_v;          /* [B][p_stride]                                           */
+    float *act;                      /* [B][3][n_cap][128]                                      */
+    float *heads;                    /* [B][n_cap][16]                                          */
+    float *d2x; int *idx_x;          /* [B][n_cap]                                              */
+    float *d2y; int *idx_y;          /* [B][t_cap]                                              */
+    const float *adam_tab;           /* [iters+1][2]: {neg_step, bc2_sqrt} for t = 1..iters     */
+} ndp_engine;
+
+/* Launch n_ticks ticks starting at tick index tick0 (parity selects the state buffer read).
+ * The caller initialises state[tick0 & 1] (level 0, iter 0, break_counter 0, loss_prev 1e6, cur 0).
+ * Asynchronous on `stream`; read state[(tick0 + n_ticks) & 1] after synchronising.              */
+int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NDP_HIP_H */

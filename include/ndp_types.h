@@ -20,6 +20,12 @@
 #ifndef NDP_TYPES_H
 #define NDP_TYPES_H
 
+#if defined(__HIPCC__)
+#define NDP_HD __host__ __device__
+#else
+#define NDP_HD
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -36,29 +42,29 @@ typedef struct ndp_layer_desc {
     float mlp_scale;  /* 0.001 (nets.py:107)                                              */
 } ndp_layer_desc;
 
-static inline int ndp_n_rot(const ndp_layer_desc *d) {
+NDP_HD static inline int ndp_n_rot(const ndp_layer_desc *d) {
     if (d->motion == NDP_MOTION_SFLOW) return 0;
     return d->rotfmt == NDP_ROT_QUATERNION ? 4 : (d->rotfmt == NDP_ROT_6D ? 6 : 3);
 }
-static inline int ndp_n_heads(const ndp_layer_desc *d) {
+NDP_HD static inline int ndp_n_heads(const ndp_layer_desc *d) {
     return ndp_n_rot(d) + (d->motion == NDP_MOTION_SIM3 ? 1 : 0) + 3 + (d->nonrigidity ? 1 : 0);
 }
-static inline int ndp_head_row_scale(const ndp_layer_desc *d) { return ndp_n_rot(d); }
-static inline int ndp_head_row_trn(const ndp_layer_desc *d) {
+NDP_HD static inline int ndp_head_row_scale(const ndp_layer_desc *d) { return ndp_n_rot(d); }
+NDP_HD static inline int ndp_head_row_trn(const ndp_layer_desc *d) {
     return ndp_n_rot(d) + (d->motion == NDP_MOTION_SIM3 ? 1 : 0);
 }
-static inline int ndp_head_row_nr(const ndp_layer_desc *d) { return ndp_head_row_trn(d) + 3; }
+NDP_HD static inline int ndp_head_row_nr(const ndp_layer_desc *d) { return ndp_head_row_trn(d) + 3; }
 
 /* offsets (in floats) inside one level's flat parameter block */
-static inline int ndp_off_W0(const ndp_layer_desc *d) { (void)d; return 0; }
-static inline int ndp_off_b0(const ndp_layer_desc *d) { return d->width * 6; }
-static inline int ndp_off_Wi(const ndp_layer_desc *d, int i /*1-based*/) {
+NDP_HD static inline int ndp_off_W0(const ndp_layer_desc *d) { (void)d; return 0; }
+NDP_HD static inline int ndp_off_b0(const ndp_layer_desc *d) { return d->width * 6; }
+NDP_HD static inline int ndp_off_Wi(const ndp_layer_desc *d, int i /*1-based*/) {
     return d->width * 7 + (i - 1) * (d->width * d->width + d->width);
 }
-static inline int ndp_off_bi(const ndp_layer_desc *d, int i) { return ndp_off_Wi(d, i) + d->width * d->width; }
-static inline int ndp_off_Wh(const ndp_layer_desc *d) { return ndp_off_Wi(d, d->n_hidden + 1); }
-static inline int ndp_off_bh(const ndp_layer_desc *d) { return ndp_off_Wh(d) + ndp_n_heads(d) * d->width; }
-static inline int ndp_param_count(const ndp_layer_desc *d) { return ndp_off_bh(d) + ndp_n_heads(d); }
+NDP_HD static inline int ndp_off_bi(const ndp_layer_desc *d, int i) { return ndp_off_Wi(d, i) + d->width * d->width; }
+NDP_HD static inline int ndp_off_Wh(const ndp_layer_desc *d) { return ndp_off_Wi(d, d->n_hidden + 1); }
+NDP_HD static inline int ndp_off_bh(const ndp_layer_desc *d) { return ndp_off_Wh(d) + ndp_n_heads(d) * d->width; }
+NDP_HD static inline int ndp_param_count(const ndp_layer_desc *d) { return ndp_off_bh(d) + ndp_n_heads(d); }
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,264 @@
+"""GPU parity tests: the HIP path (through the C ABI of libndp_hip.so) against the CPU oracle on the
+same seeded inputs, and against the golden vectors captured from the reference.
+
+Bar (BASELINE.json north_star): integer/index results bit-exact; floating point within 1e-4 on
+warped coordinates -- tolerances are written at each assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests._helpers import VARIANTS, seeded_pyramid, scale_heads, rel_err
+
+pytestmark = pytest.mark.gpu
+K0 = -8
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from deformationpyramid_amd import _native
+    _native.lib()            # must load: no fallback
+    return torch.device("cuda:0")
+
+
+def O():
+    from oracle import ndp_oracle
+    return ndp_oracle
+
+
+def cdesc(d):
+    return O().make_desc(d.width, d.n_hidden, d.motion, d.rotfmt, d.nonrigidity, d.mlp_scale)
+
+
+def cloud(n, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(n, 3, generator=g) - 0.5) * scale).contiguous()
+
+
+# ------------------------------------------------------------------------------- level forward
+@pytest.mark.parametrize("tag", list(VARIANTS))
+@pytest.mark.parametrize("n", [1, 63, 256, 1000])
+def test_level_fwd_matches_oracle(dev, tag, n):
+    from deformationpyramid_amd import ops
+    pyr = seeded_pyramid(5, **VARIANTS[tag])
+    x = cloud(n, 17)
+    for lvl in (0, 3, 8):
+        scale_heads(pyr, lvl, 30.0)
+        d = pyr.descs[lvl]
+        p = pyr.store[lvl].clone()
+        ref = O().level_fwd(cdesc(d), p[:d.param_count].numpy(), lvl, K0, x.numpy())
+        got = ops.level_fwd(d, p.to(dev), lvl, K0, x.to(dev)).cpu().numpy()
+        assert np.abs(got - ref).max() < 2e-6, (tag, lvl, n)          # warped coordinates, abs
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_level_fwd_golden_from_reference(dev, golden, tag):
+    from deformationpyramid_amd import ops
+    g = golden("F2_layer_forward")
+    pyr = seeded_pyramid(int(g["seed"]), **VARIANTS[tag])
+    levels = (0, 4, 8) if tag in ("se3aa", "sim3eu") else (4,)
+    x = torch.from_numpy(g["x"]).to(dev)
+    for lvl in levels:
+        scale_heads(pyr, lvl, float(g["head_scale"]))
+    for lvl in levels:
+        d = pyr.descs[lvl]
+        got = ops.level_fwd(d, pyr.store[lvl].to(dev), lvl, K0, x).cpu().numpy()
+        assert np.abs(got - g[f"{tag}.L{lvl}.out"]).max() < 1e-5
+    full = ops.pyramid_fwd(pyr.descs[0], 9, K0, pyr.store.to(dev), x).cpu().numpy()
+    assert np.abs(full - g[f"{tag}.full_out"]).max() < 1e-4          # north_star tolerance on warped coords
+
+
+# ------------------------------------------------------------------------------ level backward
+@pytest.mark.parametrize("tag", list(VARIANTS))
+@pytest.mark.parametrize("n,n_part", [(64, 1), (1000, 3), (1000, 16), (2000, 8)])
+def test_level_bwd_matches_oracle(dev, tag, n, n_part):
+    from deformationpyramid_amd import ops
+    pyr = seeded_pyramid(6, **VARIANTS[tag])
+    lvl = 4
+    scale_heads(pyr, lvl, 30.0)
+    d = pyr.descs[lvl]
+    x = cloud(n, 23)
+    gsrc = cloud(n, 29, scale=2.0)
+    p = pyr.store[lvl].clone()
+    ref = O().level_bwd(cdesc(d), p[:d.param_count].numpy(), lvl, K0, x.numpy(), gsrc.numpy(), nthreads=4)
+    out, act, heads = ops.level_fwd(d, p.to(dev), lvl, K0, x.to(dev), save=True)
+    got = ops.level_bwd(d, p.to(dev), lvl, K0, x.to(dev), act, heads, gsrc.to(dev), n_part=n_part).cpu().numpy()
+    for name, off, shape in d.named_slices():
+        sz = int(np.prod(shape))
+        e = rel_err(got[off:off + sz], ref[off:off + sz])
+        assert e < 1e-4, (tag, name, e)                                # fp32 summation-order class
+
+
+def test_level_bwd_golden_from_reference(dev, golden):
+    from deformationpyramid_amd import ops
+    g = golden("F2_layer_forward")
+    x = torch.from_numpy(g["x"]).to(dev)
+    coef = torch.linspace(-1.0, 1.0, 256 * 3).reshape(256, 3).to(dev)
+    for tag in ("se3aa", "sim3eu", "sflow"):
+        pyr = seeded_pyramid(int(g["seed"]), **VARIANTS[tag])
+        lvl = 4
+        scale_heads(pyr, lvl, float(g["head_scale"]))
+        d = pyr.descs[lvl]
+        p = pyr.store[lvl].to(dev)
+        _, act, heads = ops.level_fwd(d, p, lvl, K0, x, save=True)
+        got = ops.level_bwd(d, p, lvl, K0, x, act, heads, coef).cpu().numpy()
+        for name, off, shape in d.named_slices():
+            ref = g[f"{tag}.L{lvl}.grad.{name}"]
+            e = rel_err(got[off:off + ref.size].reshape(ref.shape), ref)
+            assert e < 2e-4, (tag, name, e)
+
+
+# ------------------------------------------------------------------------------------ Chamfer
+@pytest.mark.parametrize("S,T", [(300, 257), (1, 5), (2000, 2000), (1025, 3000)])
+def test_chamfer_nn_bit_exact(dev, S, T):
+    from deformationpyramid_amd import ops
+    x, y = cloud(S, 31), cloud(T, 37, scale=1.1)
+    r = O().chamfer(x.numpy(), y.numpy(), nthreads=4)
+    d2x, ix, d2y, iy = [t.cpu().numpy() for t in ops.chamfer_nn(x.to(dev), y.to(dev))]
+    np.testing.assert_array_equal(ix, r["idx_x"])
+    np.testing.assert_array_equal(iy, r["idx_y"])
+    np.testing.assert_array_equal(d2x, r["d2x"])                       # same fma chain -> same bits
+    np.testing.assert_array_equal(d2y, r["d2y"])
+
+
+def test_chamfer_nn_ties_take_lowest_index(dev):
+    from deformationpyramid_amd import ops
+    y = cloud(700, 41)
+    y = torch.cat([y, y, y[:100]]).contiguous()                         # every reference point duplicated
+    x = cloud(333, 43)
+    _, ix, _, iy = ops.chamfer_nn(x.to(dev), y.to(dev))
+    r = O().chamfer(x.numpy(), y.numpy())
+    np.testing.assert_array_equal(ix.cpu().numpy(), r["idx_x"])
+    assert ix.max().item() < 700                                        # never a later duplicate
+    np.testing.assert_array_equal(iy.cpu().numpy(), r["idx_y"])
+
+
+@pytest.mark.parametrize("trunc", [1e9, 0.01])
+def test_chamfer_loss_and_grad(dev, golden, trunc):
+    from deformationpyramid_amd import ops
+    g = golden("F3_chamfer")
+    tag = "full" if trunc > 1 else "trunc"
+    x, y = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["y"]).to(dev)
+    loss, gx, nn = ops.chamfer_l1(x, y, trunc)
+    np.testing.assert_array_equal(nn[1].cpu().numpy(), g[f"{tag}.idx_x"])
+    np.testing.assert_array_equal(nn[3].cpu().numpy(), g[f"{tag}.idx_y"])
+    assert abs(loss.item() - float(g[f"{tag}.loss"])) < 2e-6 * float(g[f"{tag}.loss"])
+    ref = g[f"{tag}.grad_x"]
+    assert np.abs(gx.cpu().numpy() - ref).max() < 2e-6 * np.abs(ref).max()
+    r = O().chamfer(g["x"], g["y"], trunc=trunc)
+    assert np.abs(gx.cpu().numpy() - r["gx"]).max() < 1e-7 * np.abs(ref).max() + 1e-12
+
+
+def test_chamfer_full_size_properties(dev):
+    """8192 x 8192 (BASELINE stress size): symmetry and idempotence properties, no oracle needed."""
+    from deformationpyramid_amd import ops
+    x, y = cloud(8192, 51).to(dev), cloud(8192, 53).to(dev)
+    d2x, ix, d2y, iy = ops.chamfer_nn(x, y)
+    d2x_b, ix_b, d2y_b, iy_b = ops.chamfer_nn(y, x)                      # swap roles
+    assert torch.equal(d2x, d2y_b) and torch.equal(ix, iy_b) and torch.equal(d2y, d2x_b) and torch.equal(iy, ix_b)
+    # the reported distance is the distance to the reported index, and nothing is closer
+    rec = ((x - y[ix.long()]) ** 2).sum(-1)
+    assert torch.allclose(rec, d2x, rtol=1e-5, atol=0)
+    full = torch.cdist(x[:512].double(), y.double()) ** 2
+    assert torch.all(full.min(dim=1).values.float() >= d2x[:512] * (1 - 1e-5))
+    # self-match: a cloud against itself gives zero distances and identity indices
+    d0, i0, _, _ = ops.chamfer_nn(x, x.clone())
+    assert torch.all(d0 == 0) and torch.equal(i0.long(), torch.arange(8192, device=dev))
+
+
+def test_landmark_and_adam_bit_exact(dev):
+    from deformationpyramid_amd import ops
+    x, t = cloud(200, 61), cloud(200, 67)
+    L, gx = ops.landmark_mse(x.to(dev), t.to(dev))
+    Lr, gr = O().landmark(x.numpy(), t.numpy())
+    assert abs(L.item() - float(Lr)) < 1e-6 * float(Lr)
+    np.testing.assert_array_equal(gx.cpu().numpy(), gr)
+    P = 34694
+    g = torch.Generator().manual_seed(71)
+    p = torch.randn(P, generator=g); gr_ = torch.randn(P, generator=g) * 1e-3
+    m = torch.zeros(P); v = torch.zeros(P)
+    pd, md, vd = p.to(dev), m.to(dev), v.to(dev)
+    pn, mn, vn = p.numpy().copy(), m.numpy().copy(), v.numpy().copy()
+    for step in range(1, 6):
+        gi = gr_ * step
+        ops.adam_step(pd, gi.to(dev), md, vd, step)
+        O().adam(pn, gi.numpy(), mn, vn, step)
+    np.testing.assert_array_equal(pd.cpu().numpy(), pn)                 # op-for-op the same arithmetic
+    np.testing.assert_array_equal(vd.cpu().numpy(), vn)
+
+
+# ----------------------------------------------------------------------------- batched engine
+def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3, seed=7, G=None, ratio=0.001):
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    kw = VARIANTS[tag]
+    cfg = OptConfig(m=m, iters=iters, early_stop=early_stop, w_cd=w_cd, trunc=trunc, break_threshold_ratio=ratio)
+    eng = None
+    refs = []
+    for b in range(B):
+        pyr = seeded_pyramid(seed + b, m=m, **kw)
+        d = pyr.descs[0]
+        if eng is None:
+            eng = BatchedEngine(d, cfg, B, n_cap=K + S, t_cap=max(T, 1), device=dev, G=G)
+        # slots of different sizes: slot b drops 7*b samples and 3*b targets
+        Kb, Sb, Tb = K, max(S - 7 * b, 0), max(T - 3 * b, 0)
+        src = cloud(Kb + Sb, 100 + b)
+        c, s_ = np.cos(0.2), np.sin(0.2)
+        Rz = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+        tgt = (cloud(Tb, 200 + b) @ Rz.T + torch.tensor([0.03, -0.02, 0.01])).contiguous() if Tb else None
+        lt = ((src[:Kb] + 0.04 * torch.sin(4 * src[:Kb])) @ Rz.T).contiguous() if Kb else None
+        eng.load(b, src, Kb, Sb, lt, tgt, pyr.store)
+        params_all = np.concatenate([pyr.store[i, :d.param_count].numpy() for i in range(m)])
+        refs.append(O().optimize([cdesc(d)] * m, params_all, src.numpy(), Kb, Sb,
+                                 lt.numpy() if Kb else None, tgt.numpy() if Tb else None, k0=K0, iters=iters,
+                                 w_cd=w_cd, trunc=trunc, early_stop=early_stop, nthreads=4, ratio=ratio))
+    states = eng.run_until_done(chunk=8)
+    return eng, states, refs
+
+
+@pytest.mark.parametrize("tag", ["se3aa", "sim3eu", "sflow"])
+def test_engine_fixed_work_matches_oracle(dev, tag):
+    """Early stop off, 6 iterations x 2 levels: same number of steps, parameters and points agree."""
+    eng, states, refs = _engine_vs_oracle(dev, tag, K=0, S=300, T=280, m=2, iters=6, early_stop=False, w_cd=1.0, trunc=1e9)
+    P = eng.P
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.level == 2 and list(st.evals_per_level[:2]) == [6, 6] and st.total_steps == 12
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+        got = eng.params[b, :, :P].cpu().numpy().reshape(-1)
+        # Adam's first steps move every weight by ~lr regardless of |g|: weights whose gradient is
+        # round-off noise may differ by O(lr); compare the bulk and the warped points.
+        diff = np.abs(got - ref["params_all"])
+        assert np.mean(diff < 1e-4) > 0.97, np.mean(diff < 1e-4)
+        pts = eng.final_points(b, st).cpu().numpy()
+        assert np.abs(pts - ref["pts"]).max() < 1e-4                     # north_star: warped coordinates
+
+
+def test_engine_early_stop_counts_match_oracle(dev):
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=256, T=256, m=3, iters=60, early_stop=True,
+                                          w_cd=1.0, trunc=1e9, ratio=0.01)
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.level == 3
+        assert list(st.evals_per_level[:3]) == list(ref["iters_per_level"]), (b, list(st.evals_per_level[:3]), ref["iters_per_level"])
+        pts = eng.final_points(b, st).cpu().numpy()
+        assert np.abs(pts - ref["pts"]).max() < 5e-4
+
+
+def test_engine_landmark_only_and_mixed(dev):
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=150, S=0, T=0, m=2, iters=5, early_stop=False, w_cd=0.0, trunc=0.25)
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.total_steps == 10
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+        assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=70, S=200, T=222, m=2, iters=4, early_stop=False, w_cd=0.5, trunc=0.05)
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+        assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+
+
+def test_engine_is_deterministic_and_G_independent_in_loss(dev):
+    e1, s1, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=2)
+    e2, s2, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=2)
+    assert torch.equal(e1.params, e2.params)                              # bit-reproducible run to run
+    e3, s3, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=8)
+    assert abs(s1[0].loss - s3[0].loss) < 1e-5 * abs(s1[0].loss)
