@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- pairs/sec (+ ms/iteration) of NDP registration on synthetic 8192-point pairs.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One *step* registers `--slots` (default 64) synthetic 8192-point pairs per GPU with the shipped
+NDP.yaml settings (SE3 / axis-angle, m = 9 levels, 2000 samples per cloud, lr 0.01, early stop on):
+per pair the full Registration.register() work -- pyramid init, centring, sampling, the level/Adam
+loop on the device, and the final warp of all 8192 source points.  The point clouds are resident in
+HBM before the timed region.  Pairs shard over ranks (weak scaling: the same number of pairs per
+GPU); the only collective is the final all-reduce of the aggregate (RCCL).
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task statement / DESIGN.md).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from deformationpyramid_amd.config import load_config            # noqa: E402
+from deformationpyramid_amd.loss import compute_flow_metrics     # noqa: E402
+from deformationpyramid_amd.registration import Registration     # noqa: E402
+from deformationpyramid_amd.synthetic import synthetic_pair      # noqa: E402
+
+FP32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md)
+FLOP_FWD_PT = 68608
+FLOP_BWD_PT = 135680
+FLOP_NN_PAIR = 8                  # per (source, target) distance evaluation; one pass serves both directions
+
+
+def algorithmic_flops(S, T, P):
+    """F(S,T) of one pair-iteration (SURVEY.md section 8d / BASELINE.md section 3)."""
+    return (FLOP_FWD_PT + FLOP_BWD_PT) * S + FLOP_NN_PAIR * S * T + 12 * P
+
+
+def kernel_profile(model, pairs, slots, n_ticks=24):
+    """Per-kernel average launch durations (HIP events on the launch stream) over ticks in which
+    every slot is active at level 0.  Returns dict kernel -> ms per launch, plus the engine."""
+    preps = [model._prepare(s, t, None) for s, t in pairs[:slots]]
+    eng = model._engine(len(preps), preps[0])
+    for b, p in enumerate(preps):
+        eng.load(b, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.pyramid.store)
+    eng.run_ticks(4)                                  # warm-up ticks
+    ms = eng.run_ticks_timed(n_ticks)
+    st = eng.read_states()
+    active = sum(1 for s in st if s.level == 0)
+    names = ["k_eng_fwd", "k_eng_nn", "k_eng_bwd", "k_eng_update"]
+    return {k: v / n_ticks for k, v in zip(names, ms)}, eng, preps, active
+
+
+def cpu_baseline(cfg, src, tgt):
+    """The oracle (oracle/ndp_oracle.c, a parity-pinned C port of the reference path) timed on this
+    box's host cores on ONE full pair with the bench's settings."""
+    from oracle import ndp_oracle as O
+    from deformationpyramid_amd.nets import Deformation_Pyramid
+    cores = os.cpu_count() or 1
+    torch.manual_seed(0)
+    pyr = Deformation_Pyramid(depth=cfg.depth, width=cfg.width, device="cpu", k0=cfg.k0, m=cfg.m,
+                              rotation_format=cfg.rotation_format, motion=cfg.motion_type)
+    d = pyr.descs[0]
+    cd = O.make_desc(d.width, d.n_hidden, d.motion, d.rotfmt, d.nonrigidity, d.mlp_scale)
+    src = src.cpu() - src.cpu().mean(0, keepdim=True)
+    tgt = tgt.cpu() - tgt.cpu().mean(0, keepdim=True)
+    s = src[torch.randperm(src.shape[0])[: cfg.samples]].numpy()
+    t = tgt[torch.randperm(tgt.shape[0])[: cfg.samples]].numpy()
+    pa = np.concatenate([pyr.store[i, :d.param_count].numpy() for i in range(cfg.m)])
+    O.lib()
+    t0 = time.time()
+    r = O.optimize([cd] * cfg.m, pa, s, 0, s.shape[0], None, t, k0=cfg.k0, iters=cfg.iters,
+                   max_break_count=cfg.max_break_count, ratio=cfg.break_threshold_ratio, lr=cfg.lr,
+                   nthreads=cores)
+    descs = [cd] * cfg.m
+    O.pyramid_fwd(descs, cfg.k0, r["params_all"], src.numpy(), nthreads=cores)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"1 full 8192-pt pair, NDP.yaml, {int(r['steps'])} Adam iterations, {dt:.2f} s "
+                      f"({1e3 * dt / max(int(r['steps']), 1):.1f} ms/iter), OpenMP over points",
+            "ms_per_iter": 1e3 * dt / max(int(r["steps"]), 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--slots", type=int, default=64, help="pairs resident per GPU (= pairs per step per GPU)")
+    ap.add_argument("--chunk", type=int, default=16, help="ticks between host polls")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    n_gpus = max(world, 1)
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    torch.set_num_threads(max(1, (os.cpu_count() or 8) // n_gpus))
+
+    cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=local_rank)
+    B = args.slots
+    # inputs resident in HBM before the timed region
+    pairs, gts = [], []
+    for i in range(B):
+        src, tgt, flow_gt, overlap = synthetic_pair(rank * B + i)
+        pairs.append((src.to(dev), tgt.to(dev)))
+        gts.append((flow_gt, overlap))
+    model = Registration(cfg)
+    torch.manual_seed(rank)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def step():
+        return model.register_batch(pairs, slots=B, chunk=args.chunk)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    steps_total = evals_total = 0
+    last = None
+    for _ in range(args.steps):
+        last = step()
+        steps_total += sum(s.total_steps for s in model.last_states)
+        evals_total += sum(s.total_evals for s in model.last_states)
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # accuracy of the last step's pairs (not timed)
+    keys = None
+    msum = None
+    for (warped, _), (src, _), (flow_gt, overlap) in zip(last, pairs, gts):
+        mtr = compute_flow_metrics(warped - src, flow_gt.to(dev), overlap.to(dev))
+        keys = list(mtr.keys())
+        v = np.array([mtr[k] for k in keys], dtype=np.float64)
+        msum = v if msum is None else msum + v
+
+    agg = torch.tensor([float(args.steps * B), float(steps_total), float(evals_total)] + list(msum) + [float(B)],
+                       dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)          # the single data-path-free collective (RCCL)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    agg = agg.cpu().numpy()
+    elapsed = float(tmax.item())
+    n_pairs, n_steps, n_evals = agg[0], agg[1], agg[2]
+    metrics = {k: float(v / agg[-1]) for k, v in zip(keys, agg[3:-1])}
+
+    out = {
+        "metric": "point-cloud pairs/sec (8192-pt NDP registration)",
+        "value": n_pairs / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "synthetic 8192-pt pair, NDP.yaml (SE3/axis-angle, m=9, samples=2000, iters<=500, "
+                               "early stop on), full register(): init + level/Adam loop + 8192-pt final warp",
+                   "pairs_per_step_per_gpu": B, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective"},
+        "ms_per_iter": 1e3 * elapsed * n_gpus / max(n_steps, 1.0),
+        "adam_iters_per_pair": n_steps / n_pairs,
+        "loss_evals_per_pair": n_evals / n_pairs,
+        "accuracy": metrics,
+    }
+
+    if rank == 0 and n_gpus == 1 and not args.no_roofline:
+        prof, eng, preps, active = kernel_profile(model, pairs, B)
+        S, T = preps[0].S, preps[0].tgt_sample.shape[0]
+        P = eng.P
+        dom = max(prof, key=prof.get)
+        flops = {"k_eng_fwd": FLOP_FWD_PT * S, "k_eng_bwd": FLOP_BWD_PT * S, "k_eng_nn": FLOP_NN_PAIR * S * T,
+                 "k_eng_update": 12 * P}
+        ach = flops[dom] * active / (prof[dom] * 1e-3) / 1e12
+        tick_ms = sum(prof.values())
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+                           "avg_launch_ms": prof[dom], "pairs_per_launch": active,
+                           "algorithmic_flop_per_pair_launch": flops[dom]}
+        out["kernels_ms_per_tick"] = prof
+        out["tick"] = {"ms": tick_ms, "achieved_tflops": algorithmic_flops(S, T, P) * active / (tick_ms * 1e-3) / 1e12}
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        src, tgt = pairs[0]
+        out["cpu_baseline"] = cpu_baseline(cfg, src, tgt)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,6 +98,7 @@ _SIGS = {
     "ndp_landmark_mse_fwd_bwd": [V, V, I, V, V, V],
     "ndp_adam_step": [V, V, V, V, I, F, F, F, F, F, F, V],
     "ndp_engine_run": [ctypes.POINTER(Engine), I, I, V],
+    "ndp_engine_run_timed": [ctypes.POINTER(Engine), I, I, V, c_float_p],
 }
 EXPORTS = ["ndp_version", "ndp_last_error"] + list(_SIGS)
 

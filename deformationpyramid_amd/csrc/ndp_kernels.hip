@@ -1042,3 +1042,50 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
     HIP_TRY(hipGetLastError(), "engine launch");
     return 0;
 }
+
+// Profiling variant of ndp_engine_run: HIP events around every kernel of every tick, recorded on the
+// launch stream; ms_out[4] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_bwd, k_eng_update.
+// Synchronises the stream before returning.  Used by bench.py for the roofline figures only.
+extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out) {
+    if (!e || !ms_out || n_ticks < 1 || n_ticks > 4096) return fail(NDP_E_INVALID, "ndp_engine_run_timed: bad arguments");
+    if (int rc = check_desc(&e->desc)) return rc;
+    if (int rc = set_smem((const void *)k_eng_fwd)) return rc;
+    if (int rc = set_smem((const void *)k_eng_bwd)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 blk(256);
+    const dim3 g_lvl(e->G, e->B);
+    const dim3 g_nn((e->n_cap + 255) / 256 + (e->t_cap + 255) / 256, e->B);
+    const dim3 g_upd((e->P + 255) / 256, e->B);
+    const bool nn = e->w_cd != 0.f && e->d2x;
+    const int per = 5;
+    hipEvent_t *ev = new hipEvent_t[(size_t)n_ticks * per];
+    for (int i = 0; i < n_ticks * per; ++i) (void)hipEventCreate(&ev[i]);
+    for (int k = 0; k < n_ticks; ++k) {
+        const int parity = (tick0 + k) & 1;
+        hipEvent_t *q = ev + (size_t)k * per;
+        (void)hipEventRecord(q[0], s);
+        hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemBytes, s, *e, parity);
+        (void)hipEventRecord(q[1], s);
+        if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
+        (void)hipEventRecord(q[2], s);
+        hipLaunchKernelGGL(k_eng_bwd, g_lvl, blk, kSmemBytes, s, *e, parity);
+        (void)hipEventRecord(q[3], s);
+        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        (void)hipEventRecord(q[4], s);
+    }
+    hipError_t err = hipStreamSynchronize(s);
+    for (int j = 0; j < 4; ++j) ms_out[j] = 0.f;
+    if (err == hipSuccess) {
+        for (int k = 0; k < n_ticks; ++k)
+            for (int j = 0; j < 4; ++j) {
+                float ms = 0.f;
+                (void)hipEventElapsedTime(&ms, ev[(size_t)k * per + j], ev[(size_t)k * per + j + 1]);
+                ms_out[j] += ms;
+            }
+    }
+    for (int i = 0; i < n_ticks * per; ++i) (void)hipEventDestroy(ev[i]);
+    delete[] ev;
+    HIP_TRY(err, "ndp_engine_run_timed sync");
+    HIP_TRY(hipGetLastError(), "ndp_engine_run_timed launch");
+    return 0;
+}

