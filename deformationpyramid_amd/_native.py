@@ -56,7 +56,7 @@ class Engine(ctypes.Structure):
                 ("gpart", ctypes.c_void_p), ("adam_m", ctypes.c_void_p), ("adam_v", ctypes.c_void_p),
                 ("act", ctypes.c_void_p), ("heads", ctypes.c_void_p),
                 ("d2x", ctypes.c_void_p), ("idx_x", ctypes.c_void_p), ("d2y", ctypes.c_void_p),
-                ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p)]
+                ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p), ("gbuf", ctypes.c_void_p)]
 
 
 def _stale():

@@ -242,14 +242,6 @@ struct BwdJob {
     const float *g;         // dL/dx_out [n][3]            (standalone mode)
     float *gpart;           // this workgroup's partial [P]
     int n, plane, n_tiles, tile0, tile_step;
-    // engine mode: gradient of the loss computed on the fly
-    const float *x_out;     // warped points [n][3]
-    const float *ldmk_t;    // [K][3]
-    const float *tgt;       // [T][3]
-    const float *d2x; const int *idx_x;   // [S]
-    const float *d2y; const int *idx_y;   // [t_cap] (-1 padded)
-    int K, S, T, t_cap;
-    float w_cd, trunc;
 };
 
 __device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] global*/, float *dst /*LDS [64][LD]*/) {
@@ -279,11 +271,10 @@ __device__ __forceinline__ void tile_outer_128x32(const float *dz /*LDS [64][LD]
     }
 }
 
-template <bool ENGINE>
 __device__ __forceinline__ void level_bwd_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
     float *bufA = sm + L_BUFA, *bufB = sm + L_BUFB, *pe = sm + L_PE, *xs = sm + L_XS;
-    float *whs = sm + L_WH, *dO = sm + L_HO, *xw = sm + L_XW, *gs = sm + L_G;
+    float *whs = sm + L_WH, *dO = sm + L_HO, *gs = sm + L_G;
 
     const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
     const float *P = job.params;
@@ -327,75 +318,10 @@ __device__ __forceinline__ void level_bwd_body(const HeadCfg &hc, const BwdJob &
                 xs[4 * t + a] = x[a];
             }
             float g[3] = {0.f, 0.f, 0.f};
-            if (ENGINE) {
-                float w[3] = {0.f, 0.f, 0.f};
-                if (p < job.n) { w[0] = job.x_out[3 * p]; w[1] = job.x_out[3 * p + 1]; w[2] = job.x_out[3 * p + 2]; }
-                xw[4 * t] = w[0]; xw[4 * t + 1] = w[1]; xw[4 * t + 2] = w[2];
-                if (p < job.K) {
-                    const float invK = 1.0f / (float)job.K;
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) g[a] = 2.0f * (w[a] - job.ldmk_t[3 * p + a]) * invK;
-                } else if (p < job.n && job.w_cd != 0.f) {
-                    const int i = p - job.K;
-                    const float d2 = job.d2x[i];
-                    if (!(d2 >= job.trunc)) {
-                        const float *yy = job.tgt + 3 * job.idx_x[i];
-                        const float inv = 1.0f / ((float)job.S * sqrtf(d2));
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) g[a] = (w[a] - yy[a]) * inv;
-                    }
-                }
-            } else if (p < job.n) {
-                g[0] = job.g[3 * p]; g[1] = job.g[3 * p + 1]; g[2] = job.g[3 * p + 2];
-            }
+            if (p < job.n) { g[0] = job.g[3 * p]; g[1] = job.g[3 * p + 1]; g[2] = job.g[3 * p + 2]; }
             gs[4 * t] = g[0]; gs[4 * t + 1] = g[1]; gs[4 * t + 2] = g[2];
         }
         __syncthreads();
-        // ---- T2 (engine): contributions of target points whose nearest source point is in this tile,
-        //      ascending j inside each quarter, quarters folded in order (deterministic).
-        if (ENGINE) {
-            float acc[3] = {0.f, 0.f, 0.f};
-            const int i_self = base + lane - job.K;         // sample index of this thread's point
-            const bool live = (job.w_cd != 0.f) && (base + lane >= job.K) && (base + lane < job.n);
-            if (job.S > 0 && job.w_cd != 0.f) {
-                const int q4 = job.t_cap / 16;              // int4 groups per quarter
-                const int4 *iy4 = reinterpret_cast<const int4 *>(job.idx_y) + wv * q4;
-                const float wx = xw[4 * lane], wy = xw[4 * lane + 1], wz = xw[4 * lane + 2];
-                for (int j4 = 0; j4 < q4; ++j4) {
-                    const int4 v = iy4[j4];
-                    const int jb = 4 * (wv * q4 + j4);
-                    const int vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        if (live && vv[e] == i_self) {
-                            const int j = jb + e;
-                            const float d2 = job.d2y[j];
-                            if (!(d2 >= job.trunc)) {
-                                const float inv = 1.0f / ((float)job.T * sqrtf(d2));
-                                acc[0] = fmaf(wx - job.tgt[3 * j], inv, acc[0]);
-                                acc[1] = fmaf(wy - job.tgt[3 * j + 1], inv, acc[1]);
-                                acc[2] = fmaf(wz - job.tgt[3 * j + 2], inv, acc[2]);
-                            }
-                        }
-                    }
-                }
-            }
-            if (wv > 0) { float *gq = gs + wv * 256 + 4 * lane; gq[0] = acc[0]; gq[1] = acc[1]; gq[2] = acc[2]; }
-            __syncthreads();
-            if (wv == 0) {
-#pragma unroll
-                for (int a = 0; a < 3; ++a) {
-                    float s = acc[a];
-                    s += gs[256 + 4 * lane + a];
-                    s += gs[512 + 4 * lane + a];
-                    s += gs[768 + 4 * lane + a];
-                    float gv = gs[4 * lane + a] + s;
-                    if (job.K > 0 && base + lane >= job.K) gv = job.w_cd * gv;     // registration.py:197
-                    gs[4 * lane + a] = gv;
-                }
-            }
-            __syncthreads();
-        }
         // ---- T3: head backward per point -> dO (pre-multiplied by mlp_scale)
         if (t < 64) {
             const int p = base + t;
@@ -562,7 +488,7 @@ k_level_bwd(HeadCfg hc, BwdJob job, int p_stride) {
     job.tile0 = blockIdx.x;
     job.tile_step = gridDim.x;
     job.gpart += (size_t)blockIdx.x * p_stride;
-    level_bwd_body<false>(hc, job, sm);
+    level_bwd_body(hc, job, sm);
 }
 
 extern "C" __global__ void k_grad_reduce(const float *gpart, int n_part, int p_stride, int P, float *grads) {
@@ -754,76 +680,140 @@ k_eng_nn(ndp_engine e, int parity) {
     }
 }
 
-// loss -> early-stop decision (every workgroup recomputes it identically) -> backward of the live tiles
+// Loss, early-stop decision and dL/dx' for every pair (one launch per tick).
+//   workgroup (0, b): loss (registration.py:193-212; loss.py:185-258), the stop rule in double
+//                     (registration.py:226-232) and the pair's next state;
+//   every workgroup : the gradient of the loss wrt its 256 warped points -- own nearest-neighbour
+//                     term, then the targets whose nearest source point it is, in ascending target
+//                     index (the order a sequential CPU scatter-add produces), no atomics.
+#define LG_CHUNK 2048
 extern "C" __global__ void __launch_bounds__(256)
-k_eng_bwd(ndp_engine e, int parity) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int b = blockIdx.y;
+k_eng_loss(ndp_engine e, int parity) {
+    __shared__ float red[256];
+    __shared__ __attribute__((aligned(16))) int iys[LG_CHUNK];
+    const int b = blockIdx.y, t = threadIdx.x;
     const ndp_pair_state st = e.state[parity * e.B + b];
     ndp_pair_state *nst = e.state + (size_t)(parity ^ 1) * e.B + b;
     if (st.level >= e.m) {
-        if (blockIdx.x == 0 && threadIdx.x == 0) { ndp_pair_state c = st; c.decision = NDP_DEC_IDLE; *nst = c; }
+        if (blockIdx.x == 0 && t == 0) { ndp_pair_state c = st; c.decision = NDP_DEC_IDLE; *nst = c; }
         return;
     }
     const ndp_pair_geom gm = e.geom[b];
     const int n = gm.K + gm.S;
-    const float *pts = e.pts + (size_t)b * 2 * e.n_cap * 3;
-    const float *x_in = pts + (size_t)st.cur * e.n_cap * 3;
-    const float *x_out = pts + (size_t)(st.cur ^ 1) * e.n_cap * 3;
+    const float *x_out = e.pts + ((size_t)b * 2 + (st.cur ^ 1)) * e.n_cap * 3;
     const float *ldmk_t = e.ldmk_t + (size_t)b * e.n_cap * 3;
     const float *tgt = e.tgt + (size_t)b * e.t_cap * 3;
     const float *d2x = e.d2x + (size_t)b * e.n_cap, *d2y = e.d2y + (size_t)b * e.t_cap;
+    const int *idx_x = e.idx_x + (size_t)b * e.n_cap, *idx_y = e.idx_y + (size_t)b * e.t_cap;
     const bool use_cd = gm.S > 0 && e.w_cd != 0.f;
 
-    // ---- loss (registration.py:193-212; loss.py:185-258)
-    float *red = sm + L_RED;
-    float loss = 0.f;
-    if (gm.K > 0) loss = sq_sum(x_out, ldmk_t, gm.K, red) * (1.0f / (float)gm.K);
-    if (use_cd) {
-        const float sx = l1_sum(d2x, gm.S, e.trunc, red);
-        const float sy = l1_sum(d2y, gm.T, e.trunc, red);
-        const float lcd = sx / (float)gm.S + sy / (float)gm.T;
-        loss = gm.K > 0 ? loss + e.w_cd * lcd : lcd;
-    }
-    // ---- early stop (registration.py:226-232), in double like the reference's Python floats
-    int bc = st.break_counter;
-    double lp = st.loss_prev;
-    bool stop = false;
-    if (e.early_stop) {
-        const double L = (double)loss;
-        if (L < 1e-4) stop = true;
-        else {
-            if (fabs(lp - L) < lp * e.break_threshold_ratio) bc += 1;
-            if (bc >= e.max_break_count) stop = true;
-            else lp = L;
+    if (blockIdx.x == 0) {
+        float loss = 0.f;
+        if (gm.K > 0) loss = sq_sum(x_out, ldmk_t, gm.K, red) * (1.0f / (float)gm.K);
+        if (use_cd) {
+            const float sx = l1_sum(d2x, gm.S, e.trunc, red);
+            const float sy = l1_sum(d2y, gm.T, e.trunc, red);
+            const float lcd = sx / (float)gm.S + sy / (float)gm.T;
+            loss = gm.K > 0 ? loss + e.w_cd * lcd : lcd;
+        }
+        if (t == 0) {
+            int bc = st.break_counter;
+            double lp = st.loss_prev;
+            bool stop = false;
+            if (e.early_stop) {
+                const double L = (double)loss;
+                if (L < 1e-4) stop = true;
+                else {
+                    if (fabs(lp - L) < lp * e.break_threshold_ratio) bc += 1;
+                    if (bc >= e.max_break_count) stop = true;
+                    else lp = L;
+                }
+            }
+            const int decision = stop ? NDP_DEC_ADVANCE : (st.iter + 1 >= e.iters ? NDP_DEC_STEP_ADVANCE : NDP_DEC_STEP);
+            ndp_pair_state c = st;
+            c.loss = loss;
+            c.decision = decision;
+            c.total_evals = st.total_evals + 1;
+            c.step_level = st.level;
+            c.step_t = st.adam_t + 1;
+            if (decision != NDP_DEC_ADVANCE) c.total_steps = st.total_steps + 1;
+            if (decision == NDP_DEC_STEP) {
+                c.iter = st.iter + 1;
+                c.adam_t = st.adam_t + 1;
+                c.break_counter = bc;
+                c.loss_prev = lp;
+            } else {                                       // registration.py:242-249 + :179-180
+                c.evals_per_level[st.level] = st.iter + 1;
+                c.level = st.level + 1;
+                c.iter = 0;
+                c.adam_t = 0;
+                c.break_counter = 0;
+                c.loss_prev = 1e6;
+                c.cur = st.cur ^ 1;
+            }
+            *nst = c;
         }
     }
-    const int decision = stop ? NDP_DEC_ADVANCE : (st.iter + 1 >= e.iters ? NDP_DEC_STEP_ADVANCE : NDP_DEC_STEP);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        ndp_pair_state c = st;
-        c.loss = loss;
-        c.decision = decision;
-        c.total_evals = st.total_evals + 1;
-        c.step_level = st.level;
-        c.step_t = st.adam_t + 1;
-        if (decision != NDP_DEC_ADVANCE) c.total_steps = st.total_steps + 1;
-        if (decision == NDP_DEC_STEP) {
-            c.iter = st.iter + 1;
-            c.adam_t = st.adam_t + 1;
-            c.break_counter = bc;
-            c.loss_prev = lp;
-        } else {                                       // registration.py:242-249 + :179-180
-            c.evals_per_level[st.level] = st.iter + 1;
-            c.level = st.level + 1;
-            c.iter = 0;
-            c.adam_t = 0;
-            c.break_counter = 0;
-            c.loss_prev = 1e6;
-            c.cur = st.cur ^ 1;
+    // ---- gradient of the loss wrt the warped points of this workgroup
+    const int p = blockIdx.x * 256 + t;
+    if (blockIdx.x * 256 >= n) return;
+    float *gout = e.gbuf + ((size_t)b * e.n_cap + p) * 3;
+    float w[3] = {0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f};
+    if (p < n) { w[0] = x_out[3 * p]; w[1] = x_out[3 * p + 1]; w[2] = x_out[3 * p + 2]; }
+    const int i_self = p - gm.K;                     // sample index (negative for landmarks)
+    if (p < gm.K) {
+        const float invK = 1.0f / (float)gm.K;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[a] = 2.0f * (w[a] - ldmk_t[3 * p + a]) * invK;
+    } else if (p < n && use_cd) {
+        const float d2 = d2x[i_self];
+        if (!(d2 >= e.trunc)) {
+            const float *yy = tgt + 3 * idx_x[i_self];
+            const float inv = 1.0f / ((float)gm.S * sqrtf(d2));
+#pragma unroll
+            for (int a = 0; a < 3; ++a) g[a] = (w[a] - yy[a]) * inv;
         }
-        *nst = c;
     }
-    if (decision == NDP_DEC_ADVANCE) return;
+    if (use_cd && blockIdx.x * 256 + 255 >= gm.K) {  // workgroup holds at least one sample
+        const bool live = p >= gm.K && p < n;
+        for (int c0 = 0; c0 < gm.T; c0 += LG_CHUNK) {
+            __syncthreads();
+            for (int j = t; j < LG_CHUNK; j += 256) iys[j] = (c0 + j < gm.T) ? idx_y[c0 + j] : -1;
+            __syncthreads();
+            const int cn = min(LG_CHUNK, gm.T - c0);
+            for (int j4 = 0; j4 < (cn + 3) / 4; ++j4) {
+                const int4 v = *reinterpret_cast<const int4 *>(iys + 4 * j4);
+                const int vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (live && vv[q] == i_self) {
+                        const int j = c0 + 4 * j4 + q;
+                        const float d2 = d2y[j];
+                        if (!(d2 >= e.trunc)) {
+                            const float inv = 1.0f / ((float)gm.T * sqrtf(d2));
+                            g[0] = fmaf(w[0] - tgt[3 * j], inv, g[0]);
+                            g[1] = fmaf(w[1] - tgt[3 * j + 1], inv, g[1]);
+                            g[2] = fmaf(w[2] - tgt[3 * j + 2], inv, g[2]);
+                        }
+                    }
+                }
+            }
+        }
+        if (gm.K > 0 && live) { g[0] = e.w_cd * g[0]; g[1] = e.w_cd * g[1]; g[2] = e.w_cd * g[2]; }   // registration.py:197
+    }
+    if (p < n) { gout[0] = g[0]; gout[1] = g[1]; gout[2] = g[2]; }
+}
+
+// backward of the live tiles of every pair that takes an Adam step this tick
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_bwd(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y;
+    const ndp_pair_state ns = e.state[(size_t)(parity ^ 1) * e.B + b];     // written by k_eng_loss this tick
+    if (ns.decision == NDP_DEC_IDLE || ns.decision == NDP_DEC_ADVANCE) return;
+    const ndp_pair_state st = e.state[parity * e.B + b];
+    const ndp_pair_geom gm = e.geom[b];
+    const int n = gm.K + gm.S;
     const int n_tiles = (n + NDP_TILE - 1) / NDP_TILE;
     float *gpart = e.gpart + ((size_t)b * e.G + blockIdx.x) * e.p_stride;
     if ((int)blockIdx.x >= n_tiles) {                  // no tile for this workgroup: its partial is zero
@@ -834,19 +824,14 @@ k_eng_bwd(ndp_engine e, int parity) {
     BwdJob job;
     job.params = e.params + ((size_t)b * e.m + st.level) * e.p_stride;
     job.freq = level_freq(st.level, e.k0);
-    job.x_in = x_in;
+    job.x_in = e.pts + ((size_t)b * 2 + st.cur) * e.n_cap * 3;
     job.act = e.act + (size_t)b * 3 * e.n_cap * NDP_W;
     job.heads = e.heads + (size_t)b * e.n_cap * NDP_NHMAX;
-    job.g = nullptr;
+    job.g = e.gbuf + (size_t)b * e.n_cap * 3;
     job.gpart = gpart;
     job.n = n; job.plane = e.n_cap; job.n_tiles = n_tiles;
     job.tile0 = blockIdx.x; job.tile_step = gridDim.x;
-    job.x_out = x_out; job.ldmk_t = ldmk_t; job.tgt = tgt;
-    job.d2x = d2x; job.idx_x = e.idx_x + (size_t)b * e.n_cap;
-    job.d2y = d2y; job.idx_y = e.idx_y + (size_t)b * e.t_cap;
-    job.K = gm.K; job.S = gm.S; job.T = gm.T; job.t_cap = e.t_cap;
-    job.w_cd = use_cd ? e.w_cd : 0.f; job.trunc = e.trunc;
-    level_bwd_body<true>(hc, job, sm);
+    level_bwd_body(hc, job, sm);
 }
 
 // fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state)
@@ -1023,7 +1008,7 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
         e->P != ndp_param_count(&e->desc) || e->p_stride < e->P || (e->p_stride & 3))
         return fail(NDP_E_INVALID, "ndp_engine_run: inconsistent engine descriptor");
     if (!e->geom || !e->state || !e->pts || !e->params || !e->gpart || !e->adam_m || !e->adam_v || !e->act ||
-        !e->heads || !e->adam_tab)
+        !e->heads || !e->adam_tab || !e->gbuf)
         return fail(NDP_E_INVALID, "ndp_engine_run: null buffer");
     if (int rc = set_smem((const void *)k_eng_fwd)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd)) return rc;
@@ -1032,10 +1017,12 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
     const dim3 g_lvl(e->G, e->B);
     const dim3 g_nn((e->n_cap + 255) / 256 + (e->t_cap + 255) / 256, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
+    const dim3 g_loss((e->n_cap + 255) / 256, e->B);
     for (int k = 0; k < n_ticks; ++k) {
         const int parity = (tick0 + k) & 1;
         hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemBytes, s, *e, parity);
         if (e->w_cd != 0.f && e->d2x) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         hipLaunchKernelGGL(k_eng_bwd, g_lvl, blk, kSmemBytes, s, *e, parity);
         hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
     }
@@ -1044,7 +1031,7 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
 }
 
 // Profiling variant of ndp_engine_run: HIP events around every kernel of every tick, recorded on the
-// launch stream; ms_out[4] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_bwd, k_eng_update.
+// launch stream; ms_out[5] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwd, k_eng_update.
 // Synchronises the stream before returning.  Used by bench.py for the roofline figures only.
 extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out) {
     if (!e || !ms_out || n_ticks < 1 || n_ticks > 4096) return fail(NDP_E_INVALID, "ndp_engine_run_timed: bad arguments");
@@ -1057,7 +1044,8 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
     const dim3 g_nn((e->n_cap + 255) / 256 + (e->t_cap + 255) / 256, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const bool nn = e->w_cd != 0.f && e->d2x;
-    const int per = 5;
+    const dim3 g_loss((e->n_cap + 255) / 256, e->B);
+    const int per = 6;
     hipEvent_t *ev = new hipEvent_t[(size_t)n_ticks * per];
     for (int i = 0; i < n_ticks * per; ++i) (void)hipEventCreate(&ev[i]);
     for (int k = 0; k < n_ticks; ++k) {
@@ -1068,16 +1056,18 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
         (void)hipEventRecord(q[1], s);
         if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
         (void)hipEventRecord(q[2], s);
-        hipLaunchKernelGGL(k_eng_bwd, g_lvl, blk, kSmemBytes, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         (void)hipEventRecord(q[3], s);
-        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_bwd, g_lvl, blk, kSmemBytes, s, *e, parity);
         (void)hipEventRecord(q[4], s);
+        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        (void)hipEventRecord(q[5], s);
     }
     hipError_t err = hipStreamSynchronize(s);
-    for (int j = 0; j < 4; ++j) ms_out[j] = 0.f;
+    for (int j = 0; j < 5; ++j) ms_out[j] = 0.f;
     if (err == hipSuccess) {
         for (int k = 0; k < n_ticks; ++k)
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < 5; ++j) {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, ev[(size_t)k * per + j], ev[(size_t)k * per + j + 1]);
                 ms_out[j] += ms;

@@ -133,6 +133,7 @@ typedef struct ndp_engine {
     float *d2x; int *idx_x;          /* [B][n_cap]                                              */
     float *d2y; int *idx_y;          /* [B][t_cap]                                              */
     const float *adam_tab;           /* [iters+1][2]: {neg_step, bc2_sqrt} for t = 1..iters     */
+    float *gbuf;                     /* [B][n_cap][3] dL/d(warped points) of the current tick   */
 } ndp_engine;
 
 /* Launch n_ticks ticks starting at tick index tick0 (parity selects the state buffer read).
@@ -140,8 +141,8 @@ typedef struct ndp_engine {
  * Asynchronous on `stream`; read state[(tick0 + n_ticks) & 1] after synchronising.              */
 int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream);
 
-/* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[4] (HOST memory)
- * receives the summed durations of the forward, NN, loss+backward and update kernels over the
+/* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[5] (HOST memory)
+ * receives the summed durations of the forward, NN, loss/gradient, backward and update kernels over the
  * n_ticks ticks.  Synchronises `stream`.  Measurement aid for bench.py (roofline), not a product path. */
 int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out);
 
