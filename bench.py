@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 
 from deformationpyramid_amd.config import load_config            # noqa: E402
 from deformationpyramid_amd.loss import compute_flow_metrics     # noqa: E402
+from deformationpyramid_amd.parallel import aggregate            # noqa: E402
 from deformationpyramid_amd.registration import Registration     # noqa: E402
 from deformationpyramid_amd.synthetic import synthetic_pair      # noqa: E402
 
@@ -162,15 +163,10 @@ def main():
         v = np.array([mtr[k] for k in keys], dtype=np.float64)
         msum = v if msum is None else msum + v
 
-    agg = torch.tensor([float(args.steps * B), float(steps_total), float(evals_total)] + list(msum) + [float(B)],
-                       dtype=torch.float64, device=dev)
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)          # the single data-path-free collective (RCCL)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    agg = agg.cpu().numpy()
-    elapsed = float(tmax.item())
+    vals = torch.tensor([float(args.steps * B), float(steps_total), float(evals_total)] + list(msum) + [float(B)],
+                        dtype=torch.float64)
+    agg, elapsed = aggregate(vals, elapsed, dev)             # the single collective: SUM + MAX over RCCL
+    agg = agg.numpy()
     n_pairs, n_steps, n_evals = agg[0], agg[1], agg[2]
     metrics = {k: float(v / agg[-1]) for k, v in zip(keys, agg[3:-1])}
 

@@ -1,0 +1,140 @@
+"""CPU-side tests: C-ABI library loads and exports every declared symbol (no compute without a GPU),
+host logic (config, metrics, timers, synthetic data, failure without a GPU), and the 2-rank
+aggregation used by bench.py (gloo)."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_library_loads_and_exports_declared_symbols():
+    from deformationpyramid_amd import _native
+    path = _native.build()
+    L = ctypes.CDLL(path)
+    header = open(os.path.join(ROOT, "include", "ndp_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*\*?(ndp_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations found in include/ndp_hip.h"
+    assert declared == set(_native.EXPORTS), declared ^ set(_native.EXPORTS)
+    for name in declared:
+        assert getattr(L, name) is not None
+    L.ndp_version.restype = ctypes.c_int
+    assert L.ndp_version() >= 100
+
+
+def test_struct_layouts_match_the_header():
+    from deformationpyramid_amd import _native
+    assert ctypes.sizeof(_native.PairState) == 120           # 12 ints/floats, 1 double, 16 ints
+    assert _native.PairState.loss_prev.offset == 48
+    assert ctypes.sizeof(_native.PairGeom) == 16
+    assert _native.Engine.break_threshold_ratio.offset % 8 == 0
+    assert _native.Engine.geom.offset % 8 == 0
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    from deformationpyramid_amd import _native
+    from deformationpyramid_amd.layout import LayerDesc
+    L = _native.lib()
+    bad = LayerDesc(width=64).c_struct()
+    rc = L.ndp_level_fwd(ctypes.byref(bad), None, 0, -8, None, 0, None, None, None, None)
+    assert rc == -2 and b"width=128" in L.ndp_last_error()
+    ok = LayerDesc().c_struct()
+    assert L.ndp_level_fwd(ctypes.byref(ok), None, 0, -8, None, 5, None, None, None, None) == -1
+    assert L.ndp_chamfer_nn_fwd(None, 0, None, 0, None, None, None, None, None) == -1
+    quat = LayerDesc(rotfmt="quaternion").c_struct()
+    assert L.ndp_level_fwd(ctypes.byref(quat), None, 0, -8, None, 0, None, None, None, None) == -2
+
+
+def test_no_cpu_fallback():
+    from deformationpyramid_amd import ops, _native
+    from deformationpyramid_amd.config import Config
+    from deformationpyramid_amd.registration import Registration
+    with pytest.raises(_native.NdpError):
+        ops.chamfer_nn(torch.zeros(4, 3), torch.zeros(4, 3))
+    cfg = Config(deformation_model="NDP", device=torch.device("cpu"), depth=3, width=128, k0=-8, m=2, w_reg=0.0,
+                 rotation_format="axis_angle", motion_type="SE3", samples=10, iters=5, lr=0.01, max_break_count=15,
+                 break_threshold_ratio=0.001)
+    model = Registration(cfg)
+    model.load_pcds(np.zeros((20, 3), np.float32), np.zeros((20, 3), np.float32))
+    with pytest.raises(_native.NdpError):
+        model.register()
+    cfg2 = Config(cfg, deformation_model="NSFP")
+    with pytest.raises(KeyError):
+        Registration(cfg2).register()
+
+
+def test_config_files_and_join_constructor():
+    from deformationpyramid_amd.config import load_config
+    c = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=torch.device("cpu"))
+    assert (c.m, c.k0, c.depth, c.width, c.samples, c.iters) == (9, -8, 3, 128, 2000, 500)
+    assert c.motion_type == "SE3" and c.rotation_format == "axis_angle" and c.w_reg == 0.0
+    assert c.split.test == "4DMatch-F" and c.snapshot_dir == "snapshot/pyramid_level/vis"
+    l = load_config(os.path.join(ROOT, "config", "LNDP.yaml"), device=torch.device("cpu"))
+    assert l.m == 10 and l.w_cd == 0.0 and l.trunc_cd == 0.25 and l.exp_dir == "0.3"
+    # every key the hot path reads is present
+    for k in ("deformation_model", "max_break_count", "break_threshold_ratio", "depth", "width", "k0", "m", "w_reg",
+              "rotation_format", "motion_type", "samples", "lr", "iters"):
+        assert k in c and k in l
+
+
+def test_F8_flow_metrics_golden(golden):
+    from deformationpyramid_amd.loss import compute_flow_metrics
+    g = golden("F8_metrics")
+    m = compute_flow_metrics(torch.from_numpy(g["flow"]), torch.from_numpy(g["flow_gt"]), torch.from_numpy(g["overlap"]))
+    assert list(m.keys()) == list(g["keys"])
+    np.testing.assert_allclose(np.array(list(m.values())), g["vals"], rtol=1e-4, atol=1e-4)
+
+
+def test_metrics_nan_on_empty_subset_like_upstream():
+    from deformationpyramid_amd.loss import compute_flow_metrics
+    f = torch.rand(10, 3)
+    m = compute_flow_metrics(f, f + 0.01, torch.ones(10, dtype=torch.bool))
+    assert np.isnan(m["occ-epe"]) and not np.isnan(m["vis-epe"])
+
+
+def test_timers_and_meters_protocol():
+    from deformationpyramid_amd.utils import Timers, AverageMeter
+    t = Timers()
+    t.tic("registration"); t.toc("registration"); t.tictoc("ndp_engine", 0.5)
+    assert t.get_avg("ndp_engine") == 0.5 and len(t.get_strings()) == 2
+    a = AverageMeter()
+    a.update(2.0); a.update(4.0)
+    assert a.avg == 3.0 and a.count == 2
+
+
+def test_synthetic_pair_matches_the_golden_generator(golden):
+    from deformationpyramid_amd.synthetic import synthetic_pair
+    g = golden("F7_end_to_end")
+    src, tgt, flow_gt, overlap = synthetic_pair(5, n_total=2048)
+    np.testing.assert_array_equal(src.numpy(), g["src"])
+    np.testing.assert_array_equal(tgt.numpy(), g["tgt"])
+    np.testing.assert_array_equal(flow_gt.numpy(), g["flow_gt"])
+    np.testing.assert_array_equal(overlap.numpy(), g["overlap"])
+    assert 0 < overlap.sum() < overlap.numel()
+
+
+def test_chamfer_argument_validation():
+    from deformationpyramid_amd.loss import compute_truncated_chamfer_distance as cd
+    with pytest.raises(ValueError):
+        cd(torch.zeros(5, 3), torch.zeros(1, 5, 3))
+    with pytest.raises(ValueError):
+        cd(torch.zeros(1, 5, 3), torch.zeros(2, 5, 3))
+    with pytest.raises(ValueError):
+        cd(torch.zeros(1, 5, 3), torch.zeros(1, 5, 3), batch_reduction="max")
+    with pytest.raises(ValueError):
+        cd(torch.zeros(1, 5, 3), torch.zeros(1, 5, 3), weights=torch.tensor([-1.0]))
+
+
+def test_two_rank_gloo_aggregation():
+    """bench.py's pair sharding + SUM/MAX aggregation, world_size 2 on CPU (gloo)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "tests", "_gloo_worker.py")],
+                         capture_output=True, text=True, env=env, timeout=240)
+    assert "AGG_OK" in out.stdout, out.stdout + out.stderr
