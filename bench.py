@@ -49,12 +49,12 @@ def kernel_profile(model, pairs, slots, n_ticks=24):
     preps = [model._prepare(s, t, None) for s, t in pairs[:slots]]
     eng = model._engine(len(preps), preps[0])
     for b, p in enumerate(preps):
-        eng.load(b, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.pyramid.store)
+        eng.load(b, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.store)
     eng.run_ticks(4)                                  # warm-up ticks
     ms = eng.run_ticks_timed(n_ticks)
     st = eng.read_states()
     active = sum(1 for s in st if s.level == 0)
-    names = ["k_eng_fwd", "k_eng_nn", "k_eng_loss", "k_eng_bwd", "k_eng_update"]
+    names = ["k_eng_fwd", "k_eng_nn", "k_eng_loss", "k_eng_bwd2", "k_eng_bwd1", "k_eng_update"]
     return {k: v / n_ticks for k, v in zip(names, ms)}, eng, preps, active
 
 
@@ -197,7 +197,9 @@ def main():
         S, T = preps[0].S, preps[0].tgt_sample.shape[0]
         P = eng.P
         dom = max(prof, key=prof.get)
-        flops = {"k_eng_fwd": FLOP_FWD_PT * S, "k_eng_bwd": FLOP_BWD_PT * S, "k_eng_nn": FLOP_NN_PAIR * S * T,
+        # backward split by layer: bwd2 = heads (2*768 MAC) + dW2 + dh1, bwd1 = dW1 + dh0 + dW0 (768 MAC)
+        flops = {"k_eng_fwd": FLOP_FWD_PT * S, "k_eng_bwd2": 2 * (2 * 16384 + 1536) * S,
+                 "k_eng_bwd1": 2 * (2 * 16384 + 768) * S, "k_eng_nn": FLOP_NN_PAIR * S * T,
                  "k_eng_update": 12 * P, "k_eng_loss": 4 * (S + T)}
         ach = flops[dom] * active / (prof[dom] * 1e-3) / 1e12
         tick_ms = sum(prof.values())

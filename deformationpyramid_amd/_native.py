@@ -21,6 +21,7 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 NDP_MAX_LEVELS = 16
 TILE = 64
 NHMAX = 16
+HROW = 24
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_int_p = ctypes.POINTER(ctypes.c_int)
@@ -56,7 +57,7 @@ class Engine(ctypes.Structure):
                 ("gpart", ctypes.c_void_p), ("adam_m", ctypes.c_void_p), ("adam_v", ctypes.c_void_p),
                 ("act", ctypes.c_void_p), ("heads", ctypes.c_void_p),
                 ("d2x", ctypes.c_void_p), ("idx_x", ctypes.c_void_p), ("d2y", ctypes.c_void_p),
-                ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p), ("gbuf", ctypes.c_void_p)]
+                ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p), ("dO", ctypes.c_void_p)]
 
 
 def _stale():
@@ -90,7 +91,7 @@ DP = ctypes.POINTER(CLayerDesc)
 
 _SIGS = {
     "ndp_level_fwd": [DP, V, I, I, V, I, V, V, V, V],
-    "ndp_level_bwd": [DP, V, I, I, V, I, V, V, V, V, I, I, V],
+    "ndp_level_bwd": [DP, V, I, I, V, I, V, V, V, V, V, I, I, V],
     "ndp_grad_reduce": [V, I, I, I, V, V],
     "ndp_pyramid_fwd": [DP, I, I, V, I, V, I, V, V, V],
     "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],

@@ -13,7 +13,8 @@
 
 #define NDP_W      128          // hidden width the kernels are specialised for
 #define NDP_LD     132          // LDS row stride (floats) of a [64][128] tile: +4 pad => b128 reads conflict-free
-#define NDP_NHMAX  16           // row stride of the saved head outputs
+#define NDP_NHMAX  16           // head-output slots per point (rot.., scale, trn, nr; <= 11 used)
+#define NDP_HROW   24           // row stride of the saved per-point record: 16 head outputs + 6 posenc values + 2 pad
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -220,4 +221,24 @@ __device__ __forceinline__ float block_sum_256(float v, float *scratch /* >= 256
     const float r = scratch[0];
     __syncthreads();
     return r;
+}
+
+// Per-point head backward for the level kernels: recompute the head stage from the saved scaled head
+// outputs, push g = dL/dx_out through it, and emit dO = mlp_scale * dL/d(scaled outputs) (16 floats).
+// lds_row: NDP_NHMAX floats of LDS private to the calling thread (run-time row offsets live there).
+__device__ __forceinline__ void point_head_bwd(const HeadCfg &hc, const float *heads_row /*global, NDP_HROW*/,
+                                               const float *x, const float *g, float *lds_row, float *dO_row /*global*/) {
+#pragma unroll
+    for (int j = 0; j < NDP_NHMAX; j += 4)
+        *reinterpret_cast<float4 *>(lds_row + j) = *reinterpret_cast<const float4 *>(heads_row + j);
+    PointHead c;
+    float out[3];
+    head_warp_fwd(hc, lds_row, x, c, out);
+    head_warp_bwd(hc, x, c, g, lds_row);
+#pragma unroll
+    for (int j = 0; j < NDP_NHMAX; j += 4) {
+        float4 v = *reinterpret_cast<const float4 *>(lds_row + j);
+        v.x *= hc.mlp_scale; v.y *= hc.mlp_scale; v.z *= hc.mlp_scale; v.w *= hc.mlp_scale;
+        *reinterpret_cast<float4 *>(dO_row + j) = v;
+    }
 }

@@ -34,8 +34,8 @@ enum : int {
     L_BUFB = L_BUFA + 64 * NDP_LD,
     L_PE = L_BUFB + 64 * NDP_LD,          // [6][64]
     L_XS = L_PE + 6 * 64,                 // [64][4] level input x
-    L_WH = L_XS + 64 * 4,                 // [16][128] head weights
-    L_BH = L_WH + NDP_NHMAX * NDP_W,      // [16]
+    L_WH = L_XS + 64 * 4,                 // [12][128] head weights (at most 6+1+3+1 = 11 rows)
+    L_BH = L_WH + 12 * NDP_W,             // [16]
     L_HO = L_BH + NDP_NHMAX,              // [64][16] head outputs / d_o
     L_XW = L_HO + 64 * NDP_NHMAX,         // [64][4] warped x (backward)
     L_G = L_XW + 64 * 4,                  // [4][64][4] gradient partials (backward)
@@ -43,6 +43,7 @@ enum : int {
     L_TOTAL = L_RED + 256
 };
 static constexpr int kSmemBytes = L_TOTAL * 4;
+static constexpr int kSmemFwdBytes = L_XW * 4;     // forward uses the carve up to the head outputs only
 
 struct LevelJob {
     const float *params;
@@ -50,7 +51,7 @@ struct LevelJob {
     const float *x_in;
     float *x_out;
     float *act;        // [3][plane][128] or nullptr
-    float *heads;      // [plane][16] or nullptr
+    float *heads;      // [plane][NDP_HROW] or nullptr: 16 scaled head outputs + 6 posenc values
     int n;             // live points
     int plane;         // rows per activation plane (capacity, multiple of 64)
     int n_tiles;       // live tiles = ceil(n / 64)
@@ -87,6 +88,9 @@ __device__ __forceinline__ void tile_gemm_64x32(const float *in /*LDS [64][LD]*/
         acc0 = MFMA32(a0.y, w[4 * i + 1], acc0); acc1 = MFMA32(a1.y, w[4 * i + 1], acc1);
         acc0 = MFMA32(a0.z, w[4 * i + 2], acc0); acc1 = MFMA32(a1.z, w[4 * i + 2], acc1);
         acc0 = MFMA32(a0.w, w[4 * i + 3], acc0); acc1 = MFMA32(a1.w, w[4 * i + 3], acc1);
+        // keep the compiler from hoisting all 32 operand reads to the top (64 extra live VGPRs -> spills
+        // at the 256-register budget of two workgroups per CU); 4 iterations in flight are plenty
+        if ((i & 3) == 3) asm volatile("" ::: "memory");
     }
 }
 
@@ -120,7 +124,7 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
 #pragma unroll
     for (int c = 0; c < 6; ++c) w0r[c] = W0[o0 * 6 + c];
     const float bias0 = b0[o0];
-    for (int i = t; i < NDP_NHMAX * NDP_W; i += 256) whs[i] = (i < hc.nh * NDP_W) ? Wh[i] : 0.f;
+    for (int i = t; i < 12 * NDP_W; i += 256) whs[i] = (i < hc.nh * NDP_W) ? Wh[i] : 0.f;
     if (t < NDP_NHMAX) bhs[t] = (t < hc.nh) ? bh[t] : 0.f;
 
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
@@ -214,10 +218,12 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
             const int p = base + t;
             const float *o = ho + t * NDP_NHMAX;
             if (job.heads) {
+                float *hr = job.heads + (size_t)p * NDP_HROW;
 #pragma unroll
                 for (int j = 0; j < NDP_NHMAX; j += 4)
-                    *reinterpret_cast<float4 *>(job.heads + (size_t)p * NDP_NHMAX + j) =
-                        *reinterpret_cast<const float4 *>(o + j);
+                    *reinterpret_cast<float4 *>(hr + j) = *reinterpret_cast<const float4 *>(o + j);
+                *reinterpret_cast<float4 *>(hr + 16) = make_float4(pe[t], pe[64 + t], pe[128 + t], pe[192 + t]);
+                *reinterpret_cast<float4 *>(hr + 20) = make_float4(pe[256 + t], pe[320 + t], 0.f, 0.f);
             }
             if (p < job.n) {
                 PointHead c;
@@ -231,27 +237,42 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
 }
 
 // ------------------------------------------------------------------------------------------------
-// Level backward (autograd of nets.py:111-140 wrt the level's parameters)
+// Level backward (autograd of nets.py:111-140 wrt the level's parameters), split by layer so that each
+// kernel keeps only ONE 128x128 weight slice + ONE 128x128 gradient accumulator in registers
+// (<= 256 VGPR+AGPR per lane => two workgroups per CU, whose load / VALU / MFMA phases overlap):
+//   bwd2: dO -> dz2 = (dO Wh) * [h2>0] ; dWh += dO^T h2 ; dW2 += dz2^T h1 ; dh1 = dz2 W2 ;
+//         dz1 = dh1 * [h1>0]  -> written over the (now dead) h2 plane of the activation store
+//   bwd1: dW1 += dz1^T h0 ; dh0 = dz1 W1 ; dz0 = dh0 * [h0>0] ; dW0 += dz0^T pe
+// The per-point head backward (dO) is done before, one thread per point (k_head_bwd / k_eng_loss).
 // ------------------------------------------------------------------------------------------------
+enum : int {
+    LB_BUFA = 0,
+    LB_BUFB = LB_BUFA + 64 * NDP_LD,
+    LB_DO = LB_BUFB + 64 * NDP_LD,        // [64][16]
+    LB_PE = LB_DO + 64 * NDP_NHMAX,       // [6][64]
+    LB_TOTAL = LB_PE + 6 * 64
+};
+static constexpr int kSmemBwdBytes = LB_TOTAL * 4;       // 73.2 KB: two workgroups per CU
+#define NDP_NHP 12                                        // head rows carried in registers (>= 11 used)
+
 struct BwdJob {
     const float *params;
-    float freq;
-    const float *x_in;      // level input [n][3]
-    const float *act;       // [3][plane][128]
-    const float *heads;     // [plane][16]
-    const float *g;         // dL/dx_out [n][3]            (standalone mode)
+    float *act;             // [3][plane][128]; plane 2 (h2) is overwritten with dz1 by bwd2
+    const float *heads;     // [plane][NDP_HROW]
+    const float *dO;        // [plane][16]
     float *gpart;           // this workgroup's partial [P]
     int n, plane, n_tiles, tile0, tile_step;
 };
 
 __device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] global*/, float *dst /*LDS [64][LD]*/) {
     const int t = threadIdx.x;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const float4 *>(src)[t + 256 * i];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int idx = t + 256 * i;           // float4 index 0..2047
-        const int row = idx >> 5, c4 = idx & 31;
-        const float4 v = reinterpret_cast<const float4 *>(src)[idx];
-        *reinterpret_cast<float4 *>(dst + row * NDP_LD + 4 * c4) = v;
+        *reinterpret_cast<float4 *>(dst + (idx >> 5) * NDP_LD + 4 * (idx & 31)) = v[i];
     }
 }
 
@@ -271,91 +292,52 @@ __device__ __forceinline__ void tile_outer_128x32(const float *dz /*LDS [64][LD]
     }
 }
 
-__device__ __forceinline__ void level_bwd_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
-    float *bufA = sm + L_BUFA, *bufB = sm + L_BUFB, *pe = sm + L_PE, *xs = sm + L_XS;
-    float *whs = sm + L_WH, *dO = sm + L_HO, *gs = sm + L_G;
-
-    const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
-    const float *P = job.params;
-    const float *W1 = P + ndp_off_Wi(&dd, 1), *W2 = P + ndp_off_Wi(&dd, 2);
-    const float *Wh = P + ndp_off_Wi(&dd, 3);
-
-    float w1t[64], w2t[64];
-    load_w_bwd(W1, wv, l31, h, w1t);
-    load_w_bwd(W2, wv, l31, h, w2t);
-    for (int i = t; i < NDP_NHMAX * NDP_W; i += 256) whs[i] = (i < hc.nh * NDP_W) ? Wh[i] : 0.f;
-
-    f32x16 dW1[4], dW2[4];
+__device__ __forceinline__ void store_dW(float *g, const f32x16 (&dW)[4], int wv, int l31, int h) {
+    const int col = 32 * wv + l31;
 #pragma unroll
     for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dW1[m][r] = 0.f; dW2[m][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) g[(32 * m + mfma_row(r, h)) * NDP_W + col] = dW[m][r];
+}
+
+__device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *bufA = sm + LB_BUFA, *bufB = sm + LB_BUFB, *dOs = sm + LB_DO;
+    const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
+    const float *P = job.params;
+    const float *W2 = P + ndp_off_Wi(&dd, 2), *Wh = P + ndp_off_Wi(&dd, 3);
+    float w2t[64];
+    load_w_bwd(W2, wv, l31, h, w2t);
+    f32x16 dW2[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW2[m][r] = 0.f;
     const int o0 = t & 127, ph = t >> 7;      // VALU phases: thread (column o0, point half ph)
-    float gW0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float gb0 = 0.f, gb1 = 0.f, gb2 = 0.f;
-    float gWh[NDP_NHMAX];
+    float whk[NDP_NHP], gWh[NDP_NHP];
 #pragma unroll
-    for (int j = 0; j < NDP_NHMAX; ++j) gWh[j] = 0.f;
-    float gbh = 0.f;                           // thread t < 16 (ph = 0 only): bias of head t
-    __syncthreads();
-    float whk[NDP_NHMAX];                      // column o0 of the head matrix, pre-scaled rows
-#pragma unroll
-    for (int j = 0; j < NDP_NHMAX; ++j) whk[j] = whs[j * NDP_W + o0];
+    for (int j = 0; j < NDP_NHP; ++j) { whk[j] = j < hc.nh ? Wh[j * NDP_W + o0] : 0.f; gWh[j] = 0.f; }
+    float gb2 = 0.f, gbh = 0.f;
 
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
-        // ---- T1: per point: x, pe, (engine: own-term gradient)
-        if (t < 64) {
-            const int p = base + t;
-            float x[3] = {0.f, 0.f, 0.f};
-            if (p < job.n) { x[0] = job.x_in[3 * p]; x[1] = job.x_in[3 * p + 1]; x[2] = job.x_in[3 * p + 2]; }
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float phs = x[a] * job.freq;
-                pe[(2 * a) * 64 + t] = sinf(phs);
-                pe[(2 * a + 1) * 64 + t] = cosf(phs);
-                xs[4 * t + a] = x[a];
-            }
-            float g[3] = {0.f, 0.f, 0.f};
-            if (p < job.n) { g[0] = job.g[3 * p]; g[1] = job.g[3 * p + 1]; g[2] = job.g[3 * p + 2]; }
-            gs[4 * t] = g[0]; gs[4 * t + 1] = g[1]; gs[4 * t + 2] = g[2];
+        // ---- dO tile and h2 tile
+        {
+            const float4 dv = reinterpret_cast<const float4 *>(job.dO + (size_t)base * NDP_NHMAX)[t];
+            load_tile_to_lds(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufA);
+            *reinterpret_cast<float4 *>(dOs + 4 * t) = dv;
         }
         __syncthreads();
-        // ---- T3: head backward per point -> dO (pre-multiplied by mlp_scale)
-        if (t < 64) {
-            const int p = base + t;
-            float o[NDP_NHMAX];
-#pragma unroll
-            for (int j = 0; j < NDP_NHMAX; j += 4) {
-                const float4 v = *reinterpret_cast<const float4 *>(job.heads + (size_t)p * NDP_NHMAX + j);
-                o[j] = v.x; o[j + 1] = v.y; o[j + 2] = v.z; o[j + 3] = v.w;
-            }
-            // stage o in LDS (run-time row offsets), recompute the head forward, then its backward
-            float *orow = dO + t * NDP_NHMAX;
-#pragma unroll
-            for (int j = 0; j < NDP_NHMAX; ++j) orow[j] = o[j];
-            PointHead c;
-            float out[3];
-            head_warp_fwd(hc, orow, xs + 4 * t, c, out);
-            const float g[3] = {gs[4 * t], gs[4 * t + 1], gs[4 * t + 2]};
-            head_warp_bwd(hc, xs + 4 * t, c, g, orow);
-#pragma unroll
-            for (int j = 0; j < NDP_NHMAX; ++j) orow[j] = hc.mlp_scale * orow[j];
-        }
-        // ---- T4: h2 tile -> bufA
-        load_tile_to_lds(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufA);
-        __syncthreads();
-        // ---- T5: dh2 = dO . Wh ; dz2 = dh2 * [h2 > 0] -> bufB ; head-weight gradients
+        // ---- dh2 = dO . Wh ; dz2 = dh2 * [h2 > 0] -> bufB ; head-weight gradients
         {
 #pragma unroll 2
             for (int pp = 0; pp < 32; ++pp) {
                 const int p = 32 * ph + pp;
                 const float hv = bufA[p * NDP_LD + o0];
-                const float *dor = dO + p * NDP_NHMAX;
+                const float *dor = dOs + p * NDP_NHMAX;
                 float dh = 0.f;
 #pragma unroll
-                for (int j4 = 0; j4 < NDP_NHMAX; j4 += 4) {
+                for (int j4 = 0; j4 < NDP_NHP; j4 += 4) {
                     const float4 d4 = *reinterpret_cast<const float4 *>(dor + j4);
                     dh = fmaf(d4.x, whk[j4], dh);         gWh[j4] = fmaf(d4.x, hv, gWh[j4]);
                     dh = fmaf(d4.y, whk[j4 + 1], dh);     gWh[j4 + 1] = fmaf(d4.y, hv, gWh[j4 + 1]);
@@ -365,60 +347,112 @@ __device__ __forceinline__ void level_bwd_body(const HeadCfg &hc, const BwdJob &
                 bufB[p * NDP_LD + o0] = hv > 0.f ? dh : 0.f;
             }
             if (t < NDP_NHMAX) {
-                for (int p = 0; p < 64; ++p) gbh += dO[p * NDP_NHMAX + t];
+                for (int p = 0; p < 64; ++p) gbh += dOs[p * NDP_NHMAX + t];
             }
         }
         __syncthreads();
-        // ---- T6: h1 tile -> bufA
+        // ---- h1 tile -> bufA
         load_tile_to_lds(job.act + ((size_t)job.plane + base) * NDP_W, bufA);
         __syncthreads();
-        // ---- T7: dW2 += dz2^T h1 ; dh1 = dz2 W2 ; db2
-        f32x16 dh0a, dh1a;
+        // ---- dW2 += dz2^T h1 ; dh1 = dz2 W2 ; db2 ; dz1 = dh1 * [h1 > 0] -> global (over the h2 plane)
         {
+            f32x16 d0, d1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dh0a[r] = 0.f; dh1a[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
             tile_outer_128x32(bufB, bufA, wv, l31, h, dW2);
-            tile_gemm_64x32(bufB, w2t, l31, h, dh0a, dh1a);
+            tile_gemm_64x32(bufB, w2t, l31, h, d0, d1);
 #pragma unroll 8
             for (int pp = 0; pp < 32; ++pp) gb2 += bufB[(32 * ph + pp) * NDP_LD + o0];
-        }
-        __syncthreads();
-        // ---- T8: dz1 = dh1 * [h1 > 0] -> bufB
-        {
+            float *dz1 = job.act + (2 * (size_t)job.plane + base) * NDP_W;
             const int col = 32 * wv + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, h);
-                bufB[row * NDP_LD + col] = bufA[row * NDP_LD + col] > 0.f ? dh0a[r] : 0.f;
-                bufB[(row + 32) * NDP_LD + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? dh1a[r] : 0.f;
+                dz1[row * NDP_W + col] = bufA[row * NDP_LD + col] > 0.f ? d0[r] : 0.f;
+                dz1[(row + 32) * NDP_W + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? d1[r] : 0.f;
             }
         }
         __syncthreads();
-        // ---- T9: h0 tile -> bufA
-        load_tile_to_lds(job.act + (size_t)base * NDP_W, bufA);
+    }
+    // ---- epilogue: this workgroup's partial of W2, b2, Wh, bh
+    float *G = job.gpart;
+    store_dW(G + ndp_off_Wi(&dd, 2), dW2, wv, l31, h);
+    float *sc = sm + LB_BUFA;
+    if (ph == 1) {
+        float *s = sc + o0 * 16;
+        s[0] = gb2;
+#pragma unroll
+        for (int j = 0; j < NDP_NHP; ++j) s[1 + j] = gWh[j];
+    }
+    __syncthreads();
+    if (ph == 0) {
+        const float *s = sc + o0 * 16;
+        G[ndp_off_bi(&dd, 2) + o0] = gb2 + s[0];
+        float *gwh = G + ndp_off_Wi(&dd, 3);
+#pragma unroll
+        for (int j = 0; j < NDP_NHP; ++j)
+            if (j < hc.nh) gwh[j * NDP_W + o0] = gWh[j] + s[1 + j];
+        if (t < hc.nh) gwh[hc.nh * NDP_W + t] = gbh;
+    }
+}
+
+__device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *bufA = sm + LB_BUFA, *bufB = sm + LB_BUFB, *pe = sm + LB_PE;
+    const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
+    const float *W1 = job.params + ndp_off_Wi(&dd, 1);
+    float w1t[64];
+    load_w_bwd(W1, wv, l31, h, w1t);
+    f32x16 dW1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW1[m][r] = 0.f;
+    const int o0 = t & 127, ph = t >> 7;
+    float gW0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float gb0 = 0.f, gb1 = 0.f;
+
+    for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
+        const int base = tile * NDP_TILE;
+        // ---- dz1 tile -> bufB, h0 tile -> bufA, posenc -> pe
+        {
+            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
+            if (t < 64) {
+                const float *hr = job.heads + (size_t)(base + t) * NDP_HROW;
+                pa = *reinterpret_cast<const float4 *>(hr + 16);
+                pb = *reinterpret_cast<const float4 *>(hr + 20);
+            }
+            load_tile_to_lds(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufB);
+            load_tile_to_lds(job.act + (size_t)base * NDP_W, bufA);
+            if (t < 64) {
+                pe[t] = pa.x; pe[64 + t] = pa.y; pe[128 + t] = pa.z; pe[192 + t] = pa.w;
+                pe[256 + t] = pb.x; pe[320 + t] = pb.y;
+            }
+        }
         __syncthreads();
-        // ---- T10: dW1 += dz1^T h0 ; dh0 = dz1 W1 ; db1
+        // ---- dW1 += dz1^T h0 ; dh0 = dz1 W1 ; db1
+        f32x16 d0, d1;
         {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { dh0a[r] = 0.f; dh1a[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
             tile_outer_128x32(bufB, bufA, wv, l31, h, dW1);
-            tile_gemm_64x32(bufB, w1t, l31, h, dh0a, dh1a);
+            tile_gemm_64x32(bufB, w1t, l31, h, d0, d1);
 #pragma unroll 8
             for (int pp = 0; pp < 32; ++pp) gb1 += bufB[(32 * ph + pp) * NDP_LD + o0];
         }
         __syncthreads();
-        // ---- T11: dz0 = dh0 * [h0 > 0] -> bufB
+        // ---- dz0 = dh0 * [h0 > 0] -> bufB
         {
             const int col = 32 * wv + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, h);
-                bufB[row * NDP_LD + col] = bufA[row * NDP_LD + col] > 0.f ? dh0a[r] : 0.f;
-                bufB[(row + 32) * NDP_LD + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? dh1a[r] : 0.f;
+                bufB[row * NDP_LD + col] = bufA[row * NDP_LD + col] > 0.f ? d0[r] : 0.f;
+                bufB[(row + 32) * NDP_LD + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? d1[r] : 0.f;
             }
         }
         __syncthreads();
-        // ---- T12: dW0 += dz0^T pe ; db0
+        // ---- dW0 += dz0^T pe ; db0
         {
 #pragma unroll 4
             for (int pp = 0; pp < 32; ++pp) {
@@ -431,50 +465,30 @@ __device__ __forceinline__ void level_bwd_body(const HeadCfg &hc, const BwdJob &
         }
         __syncthreads();
     }
-
-    // ---- epilogue: one partial per workgroup
     float *G = job.gpart;
-    {
-        float *g1 = G + ndp_off_Wi(&dd, 1), *g2 = G + ndp_off_Wi(&dd, 2);
-        const int col = 32 * wv + l31;
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = 32 * m + mfma_row(r, h);
-                g1[row * NDP_W + col] = dW1[m][r];
-                g2[row * NDP_W + col] = dW2[m][r];
-            }
-    }
-    // column-wise accumulators: fold the two point-halves (ph = 0 then ph = 1) through LDS
-    float *sc = sm + L_BUFA;      // tiles are dead now
+    store_dW(G + ndp_off_Wi(&dd, 1), dW1, wv, l31, h);
+    float *sc = sm + LB_BUFA;
     if (ph == 1) {
-        float *s = sc + o0 * 32;
+        float *s = sc + o0 * 8;
 #pragma unroll
         for (int c = 0; c < 6; ++c) s[c] = gW0[c];
-        s[6] = gb0; s[7] = gb1; s[8] = gb2;
-#pragma unroll
-        for (int j = 0; j < NDP_NHMAX; ++j) s[9 + j] = gWh[j];
+        s[6] = gb0; s[7] = gb1;
     }
     __syncthreads();
     if (ph == 0) {
-        const float *s = sc + o0 * 32;
-        float *gw0 = G + ndp_off_W0(&dd), *gb0p = G + ndp_off_b0(&dd);
+        const float *s = sc + o0 * 8;
+        float *gw0 = G + ndp_off_W0(&dd);
 #pragma unroll
         for (int c = 0; c < 6; ++c) gw0[o0 * 6 + c] = gW0[c] + s[c];
-        gb0p[o0] = gb0 + s[6];
+        G[ndp_off_b0(&dd) + o0] = gb0 + s[6];
         G[ndp_off_bi(&dd, 1) + o0] = gb1 + s[7];
-        G[ndp_off_bi(&dd, 2) + o0] = gb2 + s[8];
-        float *gwh = G + ndp_off_Wi(&dd, 3);
-        for (int j = 0; j < hc.nh; ++j) gwh[j * NDP_W + o0] = gWh[j] + s[9 + j];
-        if (t < hc.nh) gwh[hc.nh * NDP_W + t] = gbh;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // standalone kernels
 // ------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, 2)
 k_level_fwd(HeadCfg hc, LevelJob job) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     job.tile0 = blockIdx.x;
@@ -482,13 +496,39 @@ k_level_fwd(HeadCfg hc, LevelJob job) {
     level_fwd_body(hc, job, sm);
 }
 
-extern "C" __global__ void __launch_bounds__(256)
-k_level_bwd(HeadCfg hc, BwdJob job, int p_stride) {
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_level_bwd2(HeadCfg hc, BwdJob job, int p_stride) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     job.tile0 = blockIdx.x;
     job.tile_step = gridDim.x;
     job.gpart += (size_t)blockIdx.x * p_stride;
-    level_bwd_body(hc, job, sm);
+    bwd2_body(hc, job, sm);
+}
+
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_level_bwd1(HeadCfg hc, BwdJob job, int p_stride) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    job.tile0 = blockIdx.x;
+    job.tile_step = gridDim.x;
+    job.gpart += (size_t)blockIdx.x * p_stride;
+    bwd1_body(hc, job, sm);
+}
+
+// dO[p][16] = mlp_scale * dL/d(scaled head outputs) for p < n, zero rows up to `plane`
+extern "C" __global__ void __launch_bounds__(256)
+k_head_bwd(HeadCfg hc, const float *x, const float *heads, const float *g, int n, int plane, float *dO) {
+    __shared__ __attribute__((aligned(16))) float rows[256 * NDP_NHMAX];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= plane) return;
+    float *out = dO + (size_t)p * NDP_NHMAX;
+    if (p < n) {
+        const float xv[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
+        const float gv[3] = {g[3 * p], g[3 * p + 1], g[3 * p + 2]};
+        point_head_bwd(hc, heads + (size_t)p * NDP_HROW, xv, gv, rows + threadIdx.x * NDP_NHMAX, out);
+    } else {
+#pragma unroll
+        for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(out + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
 extern "C" __global__ void k_grad_reduce(const float *gpart, int n_part, int p_stride, int P, float *grads) {
@@ -499,41 +539,107 @@ extern "C" __global__ void k_grad_reduce(const float *gpart, int n_part, int p_s
     grads[i] = s;
 }
 
-// ---- brute-force 1-NN: one query per thread, references streamed through LDS in 1024-point chunks
-#define NN_CHUNK 1024
+// ---- brute-force 1-NN.  Two queries per thread; references staged in LDS as SoA (x[], y[], z[]) so that
+// one ds_read_b128 feeds four references; distances in packed fp32 (v_pk_add/mul/fma: two references per
+// instruction, same fma chain and therefore the same bits as the scalar form); the running minimum is
+// tracked per 16-reference sub-chunk with v_min3 and the exact (lowest) index is recovered by re-scanning
+// the winning sub-chunk.  ~3.7 VALU instructions per distance instead of ~10.
+#define NN_STAGE 2048
+#define NN_SUB 16
+#define NN_QPB 512                    /* queries per workgroup */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 pk_dist2(f32x2 X, f32x2 Y, f32x2 Z, f32x2 qx, f32x2 qy, f32x2 qz) {
+    const f32x2 dx = qx - X, dy = qy - Y, dz = qz - Z;
+    f32x2 dd = dx * dx;
+    dd = __builtin_elementwise_fma(dy, dy, dd);
+    dd = __builtin_elementwise_fma(dz, dz, dd);
+    return dd;
+}
+
 __device__ __forceinline__ void nn_body(const float *q, int nq, const float *r, int nr, float *d2, int *idx,
-                                        int qbase, float *sm /*[NN_CHUNK][4]*/) {
+                                        int qbase, float *sm /*[3][NN_STAGE]*/) {
     const int t = threadIdx.x;
-    const int i = qbase + t;
-    float qx = 0.f, qy = 0.f, qz = 0.f;
-    if (i < nq) { qx = q[3 * i]; qy = q[3 * i + 1]; qz = q[3 * i + 2]; }
-    float best = INFINITY;
-    int bi = -1;
-    for (int c0 = 0; c0 < nr; c0 += NN_CHUNK) {
-        const int cn = min(NN_CHUNK, nr - c0);
+    float *xs = sm, *ys = sm + NN_STAGE, *zs = sm + 2 * NN_STAGE;
+    const int i0 = qbase + t, i1 = qbase + 256 + t;
+    float qa[3] = {0.f, 0.f, 0.f}, qb[3] = {0.f, 0.f, 0.f};
+    if (i0 < nq) { qa[0] = q[3 * i0]; qa[1] = q[3 * i0 + 1]; qa[2] = q[3 * i0 + 2]; }
+    if (i1 < nq) { qb[0] = q[3 * i1]; qb[1] = q[3 * i1 + 1]; qb[2] = q[3 * i1 + 2]; }
+    const f32x2 ax = {qa[0], qa[0]}, ay = {qa[1], qa[1]}, az = {qa[2], qa[2]};
+    const f32x2 bx = {qb[0], qb[0]}, by = {qb[1], qb[1]}, bz = {qb[2], qb[2]};
+    float best0 = INFINITY, best1 = INFINITY;
+    int sc0 = -1, sc1 = -1;                               // winning sub-chunk (global index)
+    for (int c0 = 0; c0 < nr; c0 += NN_STAGE) {
+        const int cn = min(NN_STAGE, nr - c0);
+        const int cpad = (cn + NN_SUB - 1) / NN_SUB * NN_SUB;
         __syncthreads();
-        for (int j = t; j < cn; j += 256) {
-            const float *rp = r + 3 * (size_t)(c0 + j);
-            *reinterpret_cast<float4 *>(sm + 4 * j) = make_float4(rp[0], rp[1], rp[2], 0.f);
+        {   // stage: all loads first, then the LDS stores (one exposed latency, not eight)
+            float v[NN_STAGE / 256][3];
+#pragma unroll
+            for (int k = 0; k < NN_STAGE / 256; ++k) {
+                const int j = t + 256 * k;
+                const float nanv = __builtin_nanf("");
+                v[k][0] = v[k][1] = v[k][2] = nanv;       // padding never wins a minimum nor an equality
+                if (j < cn) {
+                    const float *rp = r + 3 * (size_t)(c0 + j);
+                    v[k][0] = rp[0]; v[k][1] = rp[1]; v[k][2] = rp[2];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NN_STAGE / 256; ++k) {
+                const int j = t + 256 * k;
+                if (j < cpad) { xs[j] = v[k][0]; ys[j] = v[k][1]; zs[j] = v[k][2]; }
+            }
         }
         __syncthreads();
-#pragma unroll 8
-        for (int j = 0; j < cn; ++j) {
-            const float4 rv = *reinterpret_cast<const float4 *>(sm + 4 * j);
-            const float dx = qx - rv.x, dy = qy - rv.y, dz = qz - rv.z;
-            const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            if (dd < best) { best = dd; bi = c0 + j; }
+        const int nsub = cpad / NN_SUB;
+        for (int sc = 0; sc < nsub; ++sc) {
+            float m0 = INFINITY, m1 = INFINITY;
+#pragma unroll
+            for (int u = 0; u < NN_SUB / 4; ++u) {
+                const int o = sc * NN_SUB + 4 * u;
+                const float4 X = *reinterpret_cast<const float4 *>(xs + o);
+                const float4 Y = *reinterpret_cast<const float4 *>(ys + o);
+                const float4 Z = *reinterpret_cast<const float4 *>(zs + o);
+                const f32x2 X0 = {X.x, X.y}, X1 = {X.z, X.w}, Y0 = {Y.x, Y.y}, Y1 = {Y.z, Y.w}, Z0 = {Z.x, Z.y}, Z1 = {Z.z, Z.w};
+                const f32x2 a0 = pk_dist2(X0, Y0, Z0, ax, ay, az), a1 = pk_dist2(X1, Y1, Z1, ax, ay, az);
+                const f32x2 b0 = pk_dist2(X0, Y0, Z0, bx, by, bz), b1 = pk_dist2(X1, Y1, Z1, bx, by, bz);
+                m0 = fminf(fminf(m0, a0.x), a0.y); m0 = fminf(fminf(m0, a1.x), a1.y);
+                m1 = fminf(fminf(m1, b0.x), b0.y); m1 = fminf(fminf(m1, b1.x), b1.y);
+            }
+            const int gsc = (c0 / NN_SUB) + sc;
+            if (m0 < best0) { best0 = m0; sc0 = gsc; }
+            if (m1 < best1) { best1 = m1; sc1 = gsc; }
         }
     }
-    if (i < nq) { d2[i] = best; idx[i] = bi; }
+    // exact lowest index inside the winning sub-chunk (same arithmetic -> bitwise equality is safe)
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int i = w ? i1 : i0;
+        if (i >= nq) continue;
+        const float best = w ? best1 : best0;
+        const int sc = w ? sc1 : sc0;
+        const float qx = w ? qb[0] : qa[0], qy = w ? qb[1] : qa[1], qz = w ? qb[2] : qa[2];
+        int bi = -1;
+        if (sc >= 0) {
+            const int j0 = sc * NN_SUB, j1 = min(j0 + NN_SUB, nr);
+            for (int j = j1 - 1; j >= j0; --j) {
+                const float dx = qx - r[3 * j], dy = qy - r[3 * j + 1], dz = qz - r[3 * j + 2];
+                const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                if (dd == best) bi = j;                   // descending j: the last hit is the lowest index
+            }
+        }
+        d2[i] = best;
+        idx[i] = bi;
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(256)
 k_nn(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y, int *idx_y) {
-    __shared__ __attribute__((aligned(16))) float sm[NN_CHUNK * 4];
-    const int bx = (S + 255) / 256;
-    if ((int)blockIdx.x < bx) nn_body(x, S, y, T, d2x, idx_x, blockIdx.x * 256, sm);
-    else nn_body(y, T, x, S, d2y, idx_y, (blockIdx.x - bx) * 256, sm);
+    __shared__ __attribute__((aligned(16))) float sm[3 * NN_STAGE];
+    const int bx = (S + NN_QPB - 1) / NN_QPB;
+    if ((int)blockIdx.x < bx) nn_body(x, S, y, T, d2x, idx_x, blockIdx.x * NN_QPB, sm);
+    else nn_body(y, T, x, S, d2y, idx_y, (blockIdx.x - bx) * NN_QPB, sm);
 }
 
 // sum_i sqrt(d2_i) [d2_i < trunc], deterministic block reduction (all 256 threads get the value)
@@ -625,7 +731,7 @@ extern "C" __global__ void k_adam(float *p, const float *g, float *m, float *v, 
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float level_freq(int level, int k0) { return ldexpf(1.0f, level + 1 + k0); }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, 2)
 k_eng_fwd(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.y;
@@ -643,17 +749,17 @@ k_eng_fwd(ndp_engine e, int parity) {
     job.x_in = pts + (size_t)st.cur * e.n_cap * 3;
     job.x_out = pts + (size_t)(st.cur ^ 1) * e.n_cap * 3;
     job.act = e.act + (size_t)b * 3 * e.n_cap * NDP_W;
-    job.heads = e.heads + (size_t)b * e.n_cap * NDP_NHMAX;
+    job.heads = e.heads + (size_t)b * e.n_cap * NDP_HROW;
     job.plane = e.n_cap;
     job.tile0 = blockIdx.x;
     job.tile_step = gridDim.x;
     level_fwd_body(hc, job, sm);
 }
 
-// blockIdx.x < n_cap/256: source samples -> targets;  else targets -> source samples
+// blockIdx.x < ceil(n_cap/512): source samples -> targets;  else targets -> source samples
 extern "C" __global__ void __launch_bounds__(256)
 k_eng_nn(ndp_engine e, int parity) {
-    __shared__ __attribute__((aligned(16))) float sm[NN_CHUNK * 4];
+    __shared__ __attribute__((aligned(16))) float sm[3 * NN_STAGE];
     const int b = blockIdx.y;
     const ndp_pair_state st = e.state[parity * e.B + b];
     if (st.level >= e.m) return;
@@ -661,22 +767,18 @@ k_eng_nn(ndp_engine e, int parity) {
     if (gm.S == 0 || e.w_cd == 0.f) return;
     const float *xw = e.pts + ((size_t)b * 2 + (st.cur ^ 1)) * e.n_cap * 3 + 3 * gm.K;
     const float *y = e.tgt + (size_t)b * e.t_cap * 3;
-    const int bx = (e.n_cap + 255) / 256;
+    const int bx = (e.n_cap + NN_QPB - 1) / NN_QPB;
     if ((int)blockIdx.x < bx) {
-        const int qb = blockIdx.x * 256;
+        const int qb = blockIdx.x * NN_QPB;
         if (qb >= gm.S) return;
         nn_body(xw, gm.S, y, gm.T, e.d2x + (size_t)b * e.n_cap, e.idx_x + (size_t)b * e.n_cap, qb, sm);
     } else {
-        const int qb = (blockIdx.x - bx) * 256;
+        const int qb = (blockIdx.x - bx) * NN_QPB;
         float *d2y = e.d2y + (size_t)b * e.t_cap;
         int *iy = e.idx_y + (size_t)b * e.t_cap;
-        if (qb >= gm.T) {                   // keep the -1 padding the match scan relies on
-            for (int j = qb + threadIdx.x; j < min(qb + 256, e.t_cap); j += 256) iy[j] = -1;
-            return;
-        }
-        nn_body(y, gm.T, xw, gm.S, d2y, iy, qb, sm);
-        const int j = qb + threadIdx.x;
-        if (j >= gm.T && j < e.t_cap) iy[j] = -1;
+        if (qb < gm.T) nn_body(y, gm.T, xw, gm.S, d2y, iy, qb, sm);
+        for (int j = qb + threadIdx.x; j < min(qb + NN_QPB, e.t_cap); j += 256)
+            if (j >= gm.T) iy[j] = -1;             // keep the -1 padding the gradient scan relies on
     }
 }
 
@@ -691,6 +793,8 @@ extern "C" __global__ void __launch_bounds__(256)
 k_eng_loss(ndp_engine e, int parity) {
     __shared__ float red[256];
     __shared__ __attribute__((aligned(16))) int iys[LG_CHUNK];
+    __shared__ __attribute__((aligned(16))) float tys[LG_CHUNK * 4];     // (x, y, z, d2y) of the staged targets
+    __shared__ __attribute__((aligned(16))) float rows[256 * NDP_NHMAX];  // per-thread head rows
     const int b = blockIdx.y, t = threadIdx.x;
     const ndp_pair_state st = e.state[parity * e.B + b];
     ndp_pair_state *nst = e.state + (size_t)(parity ^ 1) * e.B + b;
@@ -757,7 +861,7 @@ k_eng_loss(ndp_engine e, int parity) {
     // ---- gradient of the loss wrt the warped points of this workgroup
     const int p = blockIdx.x * 256 + t;
     if (blockIdx.x * 256 >= n) return;
-    float *gout = e.gbuf + ((size_t)b * e.n_cap + p) * 3;
+    float *dO_row = e.dO + ((size_t)b * e.n_cap + p) * NDP_NHMAX;
     float w[3] = {0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f};
     if (p < n) { w[0] = x_out[3 * p]; w[1] = x_out[3 * p + 1]; w[2] = x_out[3 * p + 2]; }
     const int i_self = p - gm.K;                     // sample index (negative for landmarks)
@@ -778,22 +882,45 @@ k_eng_loss(ndp_engine e, int parity) {
         const bool live = p >= gm.K && p < n;
         for (int c0 = 0; c0 < gm.T; c0 += LG_CHUNK) {
             __syncthreads();
-            for (int j = t; j < LG_CHUNK; j += 256) iys[j] = (c0 + j < gm.T) ? idx_y[c0 + j] : -1;
+            {   // all loads first, then the LDS stores: one exposed memory latency per chunk
+                int iv[LG_CHUNK / 256];
+                float4 tv[LG_CHUNK / 256];
+#pragma unroll
+                for (int k = 0; k < LG_CHUNK / 256; ++k) {
+                    const int j = t + 256 * k;
+                    iv[k] = -1;
+                    tv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (c0 + j < gm.T) {
+                        const float *tp = tgt + 3 * (size_t)(c0 + j);
+                        iv[k] = idx_y[c0 + j];
+                        tv[k] = make_float4(tp[0], tp[1], tp[2], d2y[c0 + j]);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < LG_CHUNK / 256; ++k) {
+                    const int j = t + 256 * k;
+                    iys[j] = iv[k];
+                    *reinterpret_cast<float4 *>(tys + 4 * j) = tv[k];
+                }
+            }
             __syncthreads();
             const int cn = min(LG_CHUNK, gm.T - c0);
+            const int key = live ? i_self : -2;       // -2 never matches (padding is -1)
+#pragma unroll 4
             for (int j4 = 0; j4 < (cn + 3) / 4; ++j4) {
                 const int4 v = *reinterpret_cast<const int4 *>(iys + 4 * j4);
-                const int vv[4] = {v.x, v.y, v.z, v.w};
+                if ((v.x == key) | (v.y == key) | (v.z == key) | (v.w == key)) {      // rare: ~1 hit per point
+                    const int vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (live && vv[q] == i_self) {
-                        const int j = c0 + 4 * j4 + q;
-                        const float d2 = d2y[j];
-                        if (!(d2 >= e.trunc)) {
-                            const float inv = 1.0f / ((float)gm.T * sqrtf(d2));
-                            g[0] = fmaf(w[0] - tgt[3 * j], inv, g[0]);
-                            g[1] = fmaf(w[1] - tgt[3 * j + 1], inv, g[1]);
-                            g[2] = fmaf(w[2] - tgt[3 * j + 2], inv, g[2]);
+                    for (int q = 0; q < 4; ++q) {
+                        if (vv[q] == key) {
+                            const float4 tv = *reinterpret_cast<const float4 *>(tys + 4 * (4 * j4 + q));
+                            if (!(tv.w >= e.trunc)) {
+                                const float inv = 1.0f / ((float)gm.T * sqrtf(tv.w));
+                                g[0] = fmaf(w[0] - tv.x, inv, g[0]);
+                                g[1] = fmaf(w[1] - tv.y, inv, g[1]);
+                                g[2] = fmaf(w[2] - tv.z, inv, g[2]);
+                            }
                         }
                     }
                 }
@@ -801,37 +928,55 @@ k_eng_loss(ndp_engine e, int parity) {
         }
         if (gm.K > 0 && live) { g[0] = e.w_cd * g[0]; g[1] = e.w_cd * g[1]; g[2] = e.w_cd * g[2]; }   // registration.py:197
     }
-    if (p < n) { gout[0] = g[0]; gout[1] = g[1]; gout[2] = g[2]; }
+    // ---- per-point head backward: dO = mlp_scale * dL/d(scaled head outputs); zero rows pad the last tile
+    if (p < n) {
+        const float *xin = e.pts + ((size_t)b * 2 + st.cur) * e.n_cap * 3 + 3 * p;
+        const float xv[3] = {xin[0], xin[1], xin[2]};
+        const HeadCfg hc = make_head_cfg(e.desc);
+        point_head_bwd(hc, e.heads + ((size_t)b * e.n_cap + p) * NDP_HROW, xv, g, rows + t * NDP_NHMAX, dO_row);
+    } else if (p < e.n_cap) {
+#pragma unroll
+        for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(dO_row + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 }
 
-// backward of the live tiles of every pair that takes an Adam step this tick
-extern "C" __global__ void __launch_bounds__(256)
-k_eng_bwd(ndp_engine e, int parity) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// backward of the live tiles of every pair that takes an Adam step this tick (two launches, see bwd2/bwd1)
+__device__ __forceinline__ bool eng_bwd_job(const ndp_engine &e, int parity, BwdJob &job, bool zero_idle_partial) {
     const int b = blockIdx.y;
     const ndp_pair_state ns = e.state[(size_t)(parity ^ 1) * e.B + b];     // written by k_eng_loss this tick
-    if (ns.decision == NDP_DEC_IDLE || ns.decision == NDP_DEC_ADVANCE) return;
-    const ndp_pair_state st = e.state[parity * e.B + b];
+    if (ns.decision == NDP_DEC_IDLE || ns.decision == NDP_DEC_ADVANCE) return false;
     const ndp_pair_geom gm = e.geom[b];
     const int n = gm.K + gm.S;
     const int n_tiles = (n + NDP_TILE - 1) / NDP_TILE;
     float *gpart = e.gpart + ((size_t)b * e.G + blockIdx.x) * e.p_stride;
     if ((int)blockIdx.x >= n_tiles) {                  // no tile for this workgroup: its partial is zero
-        for (int i = threadIdx.x; i < e.P; i += 256) gpart[i] = 0.f;
-        return;
+        if (zero_idle_partial) for (int i = threadIdx.x; i < e.P; i += 256) gpart[i] = 0.f;
+        return false;
     }
-    const HeadCfg hc = make_head_cfg(e.desc);
-    BwdJob job;
-    job.params = e.params + ((size_t)b * e.m + st.level) * e.p_stride;
-    job.freq = level_freq(st.level, e.k0);
-    job.x_in = e.pts + ((size_t)b * 2 + st.cur) * e.n_cap * 3;
+    job.params = e.params + ((size_t)b * e.m + ns.step_level) * e.p_stride;
     job.act = e.act + (size_t)b * 3 * e.n_cap * NDP_W;
-    job.heads = e.heads + (size_t)b * e.n_cap * NDP_NHMAX;
-    job.g = e.gbuf + (size_t)b * e.n_cap * 3;
+    job.heads = e.heads + (size_t)b * e.n_cap * NDP_HROW;
+    job.dO = e.dO + (size_t)b * e.n_cap * NDP_NHMAX;
     job.gpart = gpart;
     job.n = n; job.plane = e.n_cap; job.n_tiles = n_tiles;
     job.tile0 = blockIdx.x; job.tile_step = gridDim.x;
-    level_bwd_body(hc, job, sm);
+    return true;
+}
+
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_eng_bwd2(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    BwdJob job;
+    if (!eng_bwd_job(e, parity, job, true)) return;
+    bwd2_body(make_head_cfg(e.desc), job, sm);
+}
+
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_eng_bwd1(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    BwdJob job;
+    if (!eng_bwd_job(e, parity, job, false)) return;
+    bwd1_body(make_head_cfg(e.desc), job, sm);
 }
 
 // fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state)
@@ -886,10 +1031,10 @@ static int check_desc(const ndp_layer_desc *d) {
 }
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
-static int set_smem(const void *fn) {
+static int set_smem(const void *fn, int bytes) {
     static thread_local const void *done[8];
     for (auto d : done) if (d == fn) return 0;
-    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBytes), "hipFuncSetAttribute");
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute");
     for (auto &d : done) if (!d) { d = fn; break; }
     return 0;
 }
@@ -909,36 +1054,41 @@ extern "C" int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, in
     job.x_in = x; job.x_out = x_out; job.act = act; job.heads = heads;
     job.n = n; job.n_tiles = (n + NDP_TILE - 1) / NDP_TILE; job.plane = job.n_tiles * NDP_TILE;
     job.tile0 = 0; job.tile_step = 0;
-    if (int rc = set_smem((const void *)k_level_fwd)) return rc;
+    if (int rc = set_smem((const void *)k_level_fwd, kSmemFwdBytes)) return rc;
     const int grid = job.n_tiles < 1024 ? job.n_tiles : 1024;
-    hipLaunchKernelGGL(k_level_fwd, dim3(grid), dim3(256), kSmemBytes, (hipStream_t)stream, make_head_cfg(*desc), job);
+    hipLaunchKernelGGL(k_level_fwd, dim3(grid), dim3(256), kSmemFwdBytes, (hipStream_t)stream, make_head_cfg(*desc), job);
     HIP_TRY(hipGetLastError(), "k_level_fwd launch");
     return 0;
 }
 
 extern "C" int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
-                             const float *x, int n, const float *act, const float *heads, const float *g,
+                             const float *x, int n, float *act, const float *heads, const float *g, float *dO_work,
                              float *grads_part, int n_part, int p_stride, void *stream) {
+    (void)level; (void)k0;
     if (int rc = check_desc(desc)) return rc;
-    if (n <= 0 || !params || !x || !act || !heads || !g || !grads_part || n_part < 1)
+    if (n <= 0 || !params || !x || !act || !heads || !g || !dO_work || !grads_part || n_part < 1)
         return fail(NDP_E_INVALID, "ndp_level_bwd: null pointer / bad sizes");
     if (p_stride < ndp_param_count(desc)) return fail(NDP_E_INVALID, "ndp_level_bwd: p_stride < P");
-    if (!aligned16(params) || !aligned16(act) || !aligned16(heads))
-        return fail(NDP_E_INVALID, "ndp_level_bwd: params/act/heads must be 16-byte aligned");
+    if (!aligned16(params) || !aligned16(act) || !aligned16(heads) || !aligned16(dO_work))
+        return fail(NDP_E_INVALID, "ndp_level_bwd: params/act/heads/dO_work must be 16-byte aligned");
     BwdJob job;
     memset(&job, 0, sizeof job);
-    job.params = params; job.freq = ldexpf(1.0f, level + 1 + k0);
-    job.x_in = x; job.act = act; job.heads = heads; job.g = g; job.gpart = grads_part;
+    job.params = params; job.act = act; job.heads = heads; job.dO = dO_work; job.gpart = grads_part;
     job.n = n; job.n_tiles = (n + NDP_TILE - 1) / NDP_TILE; job.plane = job.n_tiles * NDP_TILE;
+    hipStream_t s = (hipStream_t)stream;
     if (n_part > job.n_tiles) {
         // partials with no tile must read as zero
         HIP_TRY(hipMemsetAsync(grads_part + (size_t)job.n_tiles * p_stride, 0,
-                               sizeof(float) * (size_t)(n_part - job.n_tiles) * p_stride, (hipStream_t)stream), "memset");
+                               sizeof(float) * (size_t)(n_part - job.n_tiles) * p_stride, s), "memset");
         n_part = job.n_tiles;
     }
-    if (int rc = set_smem((const void *)k_level_bwd)) return rc;
-    hipLaunchKernelGGL(k_level_bwd, dim3(n_part), dim3(256), kSmemBytes, (hipStream_t)stream, make_head_cfg(*desc), job, p_stride);
-    HIP_TRY(hipGetLastError(), "k_level_bwd launch");
+    if (int rc = set_smem((const void *)k_level_bwd2, kSmemBwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_level_bwd1, kSmemBwdBytes)) return rc;
+    const HeadCfg hc = make_head_cfg(*desc);
+    hipLaunchKernelGGL(k_head_bwd, dim3((job.plane + 255) / 256), dim3(256), 0, s, hc, x, heads, g, n, job.plane, dO_work);
+    hipLaunchKernelGGL(k_level_bwd2, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
+    hipLaunchKernelGGL(k_level_bwd1, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
+    HIP_TRY(hipGetLastError(), "level backward launch");
     return 0;
 }
 
@@ -971,7 +1121,7 @@ extern "C" int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const 
 extern "C" int ndp_chamfer_nn_fwd(const float *x, int S, const float *y, int T,
                                   float *d2x, int *idx_x, float *d2y, int *idx_y, void *stream) {
     if (S <= 0 || T <= 0 || !x || !y || !d2x || !idx_x || !d2y || !idx_y) return fail(NDP_E_INVALID, "ndp_chamfer_nn_fwd: bad arguments");
-    const int grid = (S + 255) / 256 + (T + 255) / 256;
+    const int grid = (S + NN_QPB - 1) / NN_QPB + (T + NN_QPB - 1) / NN_QPB;
     hipLaunchKernelGGL(k_nn, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, S, y, T, d2x, idx_x, d2y, idx_y);
     HIP_TRY(hipGetLastError(), "k_nn launch");
     return 0;
@@ -1008,22 +1158,24 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
         e->P != ndp_param_count(&e->desc) || e->p_stride < e->P || (e->p_stride & 3))
         return fail(NDP_E_INVALID, "ndp_engine_run: inconsistent engine descriptor");
     if (!e->geom || !e->state || !e->pts || !e->params || !e->gpart || !e->adam_m || !e->adam_v || !e->act ||
-        !e->heads || !e->adam_tab || !e->gbuf)
+        !e->heads || !e->adam_tab || !e->dO)
         return fail(NDP_E_INVALID, "ndp_engine_run: null buffer");
-    if (int rc = set_smem((const void *)k_eng_fwd)) return rc;
-    if (int rc = set_smem((const void *)k_eng_bwd)) return rc;
+    if (int rc = set_smem((const void *)k_eng_fwd, kSmemFwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
-    const dim3 g_nn((e->n_cap + 255) / 256 + (e->t_cap + 255) / 256, e->B);
+    const dim3 g_nn((e->n_cap + NN_QPB - 1) / NN_QPB + (e->t_cap + NN_QPB - 1) / NN_QPB, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const dim3 g_loss((e->n_cap + 255) / 256, e->B);
     for (int k = 0; k < n_ticks; ++k) {
         const int parity = (tick0 + k) & 1;
-        hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemBytes, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         if (e->w_cd != 0.f && e->d2x) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
         hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
-        hipLaunchKernelGGL(k_eng_bwd, g_lvl, blk, kSmemBytes, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
     }
     HIP_TRY(hipGetLastError(), "engine launch");
@@ -1031,43 +1183,46 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
 }
 
 // Profiling variant of ndp_engine_run: HIP events around every kernel of every tick, recorded on the
-// launch stream; ms_out[5] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwd, k_eng_update.
+// launch stream; ms_out[6] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwd2, k_eng_bwd1, k_eng_update.
 // Synchronises the stream before returning.  Used by bench.py for the roofline figures only.
 extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out) {
     if (!e || !ms_out || n_ticks < 1 || n_ticks > 4096) return fail(NDP_E_INVALID, "ndp_engine_run_timed: bad arguments");
     if (int rc = check_desc(&e->desc)) return rc;
-    if (int rc = set_smem((const void *)k_eng_fwd)) return rc;
-    if (int rc = set_smem((const void *)k_eng_bwd)) return rc;
+    if (int rc = set_smem((const void *)k_eng_fwd, kSmemFwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
-    const dim3 g_nn((e->n_cap + 255) / 256 + (e->t_cap + 255) / 256, e->B);
+    const dim3 g_nn((e->n_cap + NN_QPB - 1) / NN_QPB + (e->t_cap + NN_QPB - 1) / NN_QPB, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const bool nn = e->w_cd != 0.f && e->d2x;
     const dim3 g_loss((e->n_cap + 255) / 256, e->B);
-    const int per = 6;
+    const int per = 7;
     hipEvent_t *ev = new hipEvent_t[(size_t)n_ticks * per];
     for (int i = 0; i < n_ticks * per; ++i) (void)hipEventCreate(&ev[i]);
     for (int k = 0; k < n_ticks; ++k) {
         const int parity = (tick0 + k) & 1;
         hipEvent_t *q = ev + (size_t)k * per;
         (void)hipEventRecord(q[0], s);
-        hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemBytes, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         (void)hipEventRecord(q[1], s);
         if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
         (void)hipEventRecord(q[2], s);
         hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         (void)hipEventRecord(q[3], s);
-        hipLaunchKernelGGL(k_eng_bwd, g_lvl, blk, kSmemBytes, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         (void)hipEventRecord(q[4], s);
-        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         (void)hipEventRecord(q[5], s);
+        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        (void)hipEventRecord(q[6], s);
     }
     hipError_t err = hipStreamSynchronize(s);
-    for (int j = 0; j < 5; ++j) ms_out[j] = 0.f;
+    for (int j = 0; j < 6; ++j) ms_out[j] = 0.f;
     if (err == hipSuccess) {
         for (int k = 0; k < n_ticks; ++k)
-            for (int j = 0; j < 5; ++j) {
+            for (int j = 0; j < 6; ++j) {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, ev[(size_t)k * per + j], ev[(size_t)k * per + j + 1]);
                 ms_out[j] += ms;

@@ -58,8 +58,8 @@ class BatchedEngine:
         self.adam_m = torch.zeros(B, self.p_stride, **f32)
         self.adam_v = torch.zeros(B, self.p_stride, **f32)
         self.act = torch.zeros(B, 3, self.n_cap, 128, **f32)
-        self.heads = torch.zeros(B, self.n_cap, N.NHMAX, **f32)
-        self.gbuf = torch.zeros(B, self.n_cap, 3, **f32)
+        self.heads = torch.zeros(B, self.n_cap, N.HROW, **f32)
+        self.dO = torch.zeros(B, self.n_cap, N.NHMAX, **f32)
         self.d2x = torch.zeros(B, self.n_cap, **f32)
         self.d2y = torch.zeros(B, self.t_cap, **f32)
         self.idx_x = torch.zeros(B, self.n_cap, device=d, dtype=torch.int32)
@@ -86,7 +86,7 @@ class BatchedEngine:
         e.w_cd, e.trunc = c.w_cd, c.trunc
         e.adam_w1, e.adam_b2, e.adam_w2, e.adam_eps = 1 - 0.9, 0.999, 1 - 0.999, 1e-8
         for name in ("geom", "state", "pts", "ldmk_t", "tgt", "params", "gpart", "adam_m", "adam_v", "act", "heads",
-                     "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "gbuf"):
+                     "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "dO"):
             setattr(e, name, getattr(self, name).data_ptr())
         self.c_engine = e
 
@@ -127,8 +127,8 @@ class BatchedEngine:
         self.tick += n_ticks
 
     def run_ticks_timed(self, n_ticks):
-        """-> per-kernel summed milliseconds [fwd, nn, loss, bwd, update] (HIP events on the launch stream)."""
-        ms = (ctypes.c_float * 5)()
+        """-> per-kernel summed milliseconds [fwd, nn, loss, bwd2, bwd1, update] (HIP events on the launch stream)."""
+        ms = (ctypes.c_float * 6)()
         N.check(self.lib.ndp_engine_run_timed(ctypes.byref(self.c_engine), self.tick, int(n_ticks),
                                               N.stream_ptr(self.device), ms), "ndp_engine_run_timed")
         self.tick += n_ticks

@@ -28,27 +28,44 @@ import torch.nn as nn
 from .layout import LayerDesc
 
 
+_KAIMING_GAIN = nn.init.calculate_gain("leaky_relu", math.sqrt(5))
+
+
 def _init_level_flat(desc: LayerDesc, depth: int, out: torch.Tensor = None) -> torch.Tensor:
     """Fill one level's flat block consuming the CPU generator exactly as NDPLayer.__init__ +
     _reset_parameters do (nets.py:67-109,180-183): per nn.Linear, in module-registration order,
     the default init (kaiming_uniform_(a=sqrt(5)) on the weight, then uniform bias); afterwards
     xavier_uniform_ on every matrix in the same order.  The draws go straight into views of the
-    flat block -- no nn.Module objects are built (6.5 ms -> ~1 ms per 9-level pyramid)."""
-    W = desc.width
+    flat block with the bounds torch.nn.init computes -- no nn.Module objects are built.
+    Call under torch.no_grad()."""
     assert depth - 1 == desc.n_hidden
     flat = out if out is not None else torch.empty(desc.param_count, dtype=torch.float32)
     slices = desc.named_slices()                       # (weight, bias) pairs in registration order
     mats = []
     for (wname, woff, wshape), (bname, boff, bshape) in zip(slices[0::2], slices[1::2]):
         fan_out, fan_in = wshape
-        w = flat[woff:woff + fan_out * fan_in].view(fan_out, fan_in)
-        nn.init.kaiming_uniform_(w, a=math.sqrt(5))                       # nn.Linear.reset_parameters
-        bound = 1 / math.sqrt(fan_in) if fan_in > 0 else 0
-        nn.init.uniform_(flat[boff:boff + fan_out], -bound, bound)
-        mats.append(w)
-    for w in mats:                                                       # nets.py:180-183
-        nn.init.xavier_uniform_(w)
+        w = flat[woff:woff + fan_out * fan_in]
+        # nn.Linear.reset_parameters: kaiming_uniform_(weight, a=sqrt(5)); bias ~ U(-1/sqrt(fan_in), +)
+        kb = math.sqrt(3.0) * (_KAIMING_GAIN / math.sqrt(fan_in))
+        w.uniform_(-kb, kb)
+        bb = 1 / math.sqrt(fan_in)
+        flat[boff:boff + fan_out].uniform_(-bb, bb)
+        mats.append((w, math.sqrt(3.0) * (1.0 * math.sqrt(2.0 / float(fan_in + fan_out)))))
+    for w, a in mats:                                                    # nets.py:180-183 xavier_uniform_
+        w.uniform_(-a, a)
     return flat
+
+
+def init_pyramid_store(descs, depth, p_stride):
+    """[m, p_stride] CPU tensor with every level initialised in order (the RNG replay of
+    Deformation_Pyramid.__init__, nets.py:20-30) -- the part of the constructor the batched
+    registration path needs, without the per-name Parameter views."""
+    store = torch.empty(len(descs), p_stride, dtype=torch.float32)
+    with torch.no_grad():
+        for i, d in enumerate(descs):
+            _init_level_flat(d, depth, out=store[i, :d.param_count])
+            store[i, d.param_count:] = 0.0                # padding reads as zero
+    return store
 
 
 class NDPLevel(nn.Module):
@@ -101,11 +118,7 @@ class Deformation_Pyramid:
         self.pmax = max(d.param_count for d in self.descs) if m else 0
         self.p_stride = (self.pmax + 63) // 64 * 64          # rows stay 16-byte aligned for the kernels
         # all levels are initialised on the CPU generator first (nets.py:20-30), then moved
-        store = torch.empty(m, self.p_stride, dtype=torch.float32)
-        with torch.no_grad():
-            for i, d in enumerate(self.descs):
-                _init_level_flat(d, depth, out=store[i, :d.param_count])
-                store[i, d.param_count:] = 0.0                # padding reads as zero
+        store = init_pyramid_store(self.descs, depth, self.p_stride)
         self.store = store.to(self.device)
         self.pyramid = [NDPLevel(d, i, k0, self.store[i, :d.param_count]) for i, d in enumerate(self.descs)]
 

@@ -43,7 +43,7 @@ def level_fwd(desc: LayerDesc, params, level, k0, x, save=False):
     if save:
         c = cap(n)
         act = torch.empty(3, c, 128, device=x.device, dtype=torch.float32)
-        heads = torch.empty(c, N.NHMAX, device=x.device, dtype=torch.float32)
+        heads = torch.empty(c, N.HROW, device=x.device, dtype=torch.float32)
     cd = desc.c_struct()
     N.check(N.lib().ndp_level_fwd(ctypes.byref(cd), _p(params), int(level), int(k0), _p(x), n, _p(out),
                                   _p(act), _p(heads), N.stream_ptr(x.device)), "ndp_level_fwd")
@@ -51,7 +51,7 @@ def level_fwd(desc: LayerDesc, params, level, k0, x, save=False):
 
 
 def level_bwd(desc: LayerDesc, params, level, k0, x, act, heads, g, n_part=None):
-    """-> grads [P] (partials folded in index order on the device)."""
+    """-> grads [P] (partials folded in index order on the device).  `act` is consumed."""
     _chk(params, "params"); _chk(x, "x"); _chk(act, "act"); _chk(heads, "heads"); _chk(g, "g")
     n = x.shape[0]
     P = desc.param_count
@@ -60,10 +60,11 @@ def level_bwd(desc: LayerDesc, params, level, k0, x, act, heads, g, n_part=None)
     if n_part is None:
         n_part = min(tiles, 256)
     part = torch.empty(n_part, stride, device=x.device, dtype=torch.float32)
+    work = torch.empty(cap(n), N.NHMAX, device=x.device, dtype=torch.float32)
     cd = desc.c_struct()
     st = N.stream_ptr(x.device)
     N.check(N.lib().ndp_level_bwd(ctypes.byref(cd), _p(params), int(level), int(k0), _p(x), n, _p(act), _p(heads),
-                                  _p(g), _p(part), n_part, stride, st), "ndp_level_bwd")
+                                  _p(g), _p(work), _p(part), n_part, stride, st), "ndp_level_bwd")
     grads = torch.empty(P, device=x.device, dtype=torch.float32)
     N.check(N.lib().ndp_grad_reduce(_p(part), n_part, stride, P, _p(grads), st), "ndp_grad_reduce")
     return grads

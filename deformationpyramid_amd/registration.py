@@ -15,8 +15,9 @@ Host work stays in torch (tensor plumbing, the CPU RNG replay of the reference's
 randperm calls); the optimisation itself runs in libndp_hip.so.  There is no CPU fallback:
 config.device must be a GPU.
 """
+import queue
+import threading
 import time
-from collections import deque
 
 import numpy as np
 import torch
@@ -24,12 +25,13 @@ import torch
 from . import _native as N
 from . import ops
 from .engine import BatchedEngine, OptConfig
-from .nets import Deformation_Pyramid
+from .layout import LayerDesc
+from .nets import init_pyramid_store
 
 
 class _Prepared:
     """Everything one pair needs on the device before it enters an engine slot."""
-    __slots__ = ("src_centered", "tgt_mean", "pts", "K", "S", "ldmk_t", "tgt_sample", "pyramid", "result",
+    __slots__ = ("src_centered", "tgt_mean", "pts", "K", "S", "ldmk_t", "tgt_sample", "desc", "store", "result",
                  "state", "src_pcd")
 
 
@@ -66,7 +68,7 @@ class Registration:
         prep = self._prepare(self.src_pcd, self.tgt_pcd, self.landmarks)
         self.src_pcd = prep.src_pcd
         eng = self._engine(1, prep)
-        eng.load(0, prep.pts, prep.K, prep.S, prep.ldmk_t, prep.tgt_sample, prep.pyramid.store)
+        eng.load(0, prep.pts, prep.K, prep.S, prep.ldmk_t, prep.tgt_sample, prep.store)
         st = eng.run_until_done(chunk=32)[0]
         warped = self._finish(eng, 0, prep, st)
         self.last_state = st
@@ -77,32 +79,86 @@ class Registration:
         return warped, iter_cnt, timer
 
     # ------------------------------------------------------------------ batched extension
-    def register_batch(self, pairs, slots=64, chunk=16):
-        """pairs: iterable of (src, tgt) or (src, tgt, (ldmk_s, ldmk_t)).  Pairs are prepared in order
+    def register_batch(self, pairs, slots=64, chunk=16, prefetch=True):
+        """pairs: sequence of (src, tgt) or (src, tgt, (ldmk_s, ldmk_t)).  Pairs are prepared in order
         (so the CPU RNG stream is consumed exactly as by sequential register() calls) and optimised
-        `slots` at a time with finished slots refilled.  Returns [(warped, iter_cnt)] in input order."""
-        preps = []
-        for item in pairs:
-            src, tgt = item[0], item[1]
-            ldmk = item[2] if len(item) > 2 else None
-            if isinstance(src, np.ndarray):
-                src, tgt = torch.from_numpy(src), torch.from_numpy(tgt)
-            preps.append(self._prepare(src.to(self.device), tgt.to(self.device), ldmk))
-        if not preps:
+        `slots` at a time, finished slots being refilled.  With prefetch=True the host-side preparation
+        (RNG replay of the init, centring, sampling) runs in a producer thread ahead of the GPU.
+        Returns [(warped, iter_cnt)] in input order."""
+        pairs = list(pairs)
+        if not pairs:
             return []
-        B = min(slots, len(preps))
-        biggest = max(preps, key=lambda p: p.K + p.S)
-        widest = max(preps, key=lambda p: 0 if p.tgt_sample is None else p.tgt_sample.shape[0])
-        eng = self._engine(B, biggest, t_like=widest)
-        pending = deque(range(len(preps)))
-        active = {}
+        todo = queue.Queue(maxsize=max(2 * slots, 8))
+        preps = [None] * len(pairs)
+        dev = self._dev()
+        side = torch.cuda.Stream(dev) if prefetch else None
+
+        def produce():
+            try:
+                for i, item in enumerate(pairs):
+                    src, tgt = item[0], item[1]
+                    ldmk = item[2] if len(item) > 2 else None
+                    if isinstance(src, np.ndarray):
+                        src, tgt = torch.from_numpy(src), torch.from_numpy(tgt)
+                    if side is not None:
+                        with torch.cuda.stream(side):
+                            p = self._prepare(src.to(dev), tgt.to(dev), ldmk)
+                            ev = torch.cuda.Event()
+                            ev.record(side)
+                    else:
+                        p, ev = self._prepare(src.to(dev), tgt.to(dev), ldmk), None
+                    todo.put((i, p, ev))
+                todo.put(None)
+            except BaseException as e:       # surface producer failures in the consumer
+                todo.put(e)
+
+        if prefetch:
+            th = threading.Thread(target=produce, daemon=True)
+            th.start()
+        else:
+            # unbounded in-line preparation
+            todo = queue.Queue()
+            produce()
+
+        def next_prepared():
+            item = todo.get()
+            if item is None:
+                return None
+            if isinstance(item, BaseException):
+                raise item
+            i, p, ev = item
+            if ev is not None:
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(ev)
+                for name in ("src_centered", "tgt_mean", "pts", "ldmk_t", "tgt_sample", "src_pcd"):
+                    t = getattr(p, name)
+                    if t is not None:
+                        t.record_stream(cur)         # allocated on the producer's stream, consumed here
+            preps[i] = p
+            return i, p
+
+        first = next_prepared()
+        B = min(slots, len(pairs))
+        eng = self._engine(B, first[1], n_hint=self.config.samples + (first[1].K if first[1].K else 0))
         for slot in range(B):
-            i = pending.popleft()
-            p = preps[i]
-            eng.load(slot, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.pyramid.store)
-            active[slot] = i
+            eng.park(slot)
+        active, free, exhausted = {}, list(range(B)), False
+        nxt = first
         m = self.config.m
-        while active:
+        while True:
+            while free and not exhausted:
+                if nxt is None:
+                    nxt = next_prepared()
+                    if nxt is None:
+                        exhausted = True
+                        break
+                i, p = nxt
+                nxt = None
+                slot = free.pop()
+                eng.load(slot, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.store)
+                active[slot] = i
+            if not active:
+                break
             eng.run_ticks(chunk)
             states = eng.read_states()
             for slot in list(active):
@@ -113,13 +169,8 @@ class Registration:
                 p = preps[i]
                 p.result = self._finish(eng, slot, p, st)
                 p.state = st
-                if pending:
-                    j = pending.popleft()
-                    q = preps[j]
-                    eng.load(slot, q.pts, q.K, q.S, q.ldmk_t, q.tgt_sample, q.pyramid.store)
-                    active[slot] = j
-                else:
-                    eng.park(slot)
+                eng.park(slot)
+                free.append(slot)
         self.last_states = [p.state for p in preps]
         return [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
 
@@ -152,9 +203,8 @@ class Registration:
             raise N.NdpError("the HIP kernels are specialised for depth=3, width=128 (NDP.yaml / LNDP.yaml)")
         p = _Prepared()
         # registration.py:133-140 -- all m levels are initialised up front on the CPU generator
-        p.pyramid = Deformation_Pyramid(depth=c.depth, width=c.width, device="cpu", k0=c.k0, m=c.m,
-                                        nonrigidity_est=c.w_reg > 0, rotation_format=c.rotation_format,
-                                        motion=c.motion_type)
+        p.desc = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format)
+        p.store = init_pyramid_store([p.desc] * c.m, c.depth, (p.desc.param_count + 63) // 64 * 64)
         src_pcd = src_pcd.to(dev).float()
         tgt_pcd = tgt_pcd.to(dev).float()
         p.src_pcd = src_pcd
@@ -185,12 +235,12 @@ class Registration:
         p.result = p.state = None
         return p
 
-    def _engine(self, B, like, t_like=None):
-        t_like = t_like or like
-        n_cap = ops.cap(like.K + like.S)
-        t_cap = ops.cap(0 if t_like.tgt_sample is None else t_like.tgt_sample.shape[0])
+    def _engine(self, B, like, n_hint=0):
+        n_cap = ops.cap(max(like.K + like.S, n_hint))
+        t_cap = ops.cap(max(0 if like.tgt_sample is None else like.tgt_sample.shape[0],
+                            self.config.samples if like.S else 0))
         cfg = self._opt_config(like.K > 0)
-        desc = like.pyramid.descs[0]
+        desc = like.desc
         key = (B, n_cap, t_cap, desc, tuple(sorted(vars(cfg).items())))
         if key not in self._engines:
             self._engines.clear()                      # one resident engine at a time
@@ -201,5 +251,5 @@ class Registration:
         """registration.py:253-262: warp ALL source points through the optimised pyramid, add tgt_mean."""
         c = self.config
         store = eng.params[slot]                                                  # [m, p_stride] on device
-        warped = ops.pyramid_fwd(prep.pyramid.descs[0], c.m, c.k0, store, prep.src_centered)
+        warped = ops.pyramid_fwd(prep.desc, c.m, c.k0, store, prep.src_centered)
         return warped + prep.tgt_mean

@@ -26,6 +26,7 @@ extern "C" {
 #define NDP_E_UNSUPPORTED (-2)
 #define NDP_MAX_LEVELS    16
 #define NDP_TILE          64      /* points per tile; point capacities are multiples of this */
+#define NDP_HROW          24      /* floats per point in the saved head record                 */
 
 int ndp_version(void);                 /* 100*major + minor */
 const char *ndp_last_error(void);      /* text of the last non-zero return on this thread */
@@ -36,17 +37,19 @@ const char *ndp_last_error(void);      /* text of the last non-zero return on th
  * get_Rotation :144-161; rigid_body.py:19-56,89-119).
  *   x [n][3] -> x_out [n][3].
  *   act  (may be NULL): [3][n_cap][128] saved post-ReLU activations h0,h1,h2 for ndp_level_bwd
- *   heads(may be NULL): [n_cap][16] scaled head outputs (rot.., scale, trn, nr)
+ *   heads(may be NULL): [n_cap][NDP_HROW] per-point record: 16 scaled head outputs (rot.., scale,
+ *                       trn, nr) followed by the 6 positional-encoding values and 2 pad floats
  * n_cap = n rounded up to NDP_TILE (row count of act/heads).                                   */
 int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
                   const float *x, int n, float *x_out, float *act, float *heads, void *stream);
 
 /* Backward of one level wrt its parameters given g = dL/dx_out [n][3] (autograd of nets.py:111-140;
  * x is a detached input, registration.py:243-249).  act/heads come from ndp_level_fwd on the same
- * x and params.  grads_part [n_part][P_stride] receives n_part partial sums (deterministic: block
- * g sums tiles g, g+n_part, ...); ndp_grad_reduce or ndp_adam_step folds them in index order.   */
+ * x and params; act is CONSUMED (its h2 plane is overwritten with an intermediate).  dO_work is
+ * scratch of [n_cap][16] floats.  grads_part [n_part][P_stride] receives n_part partial sums
+ * (deterministic: workgroup g sums tiles g, g+n_part, ...); ndp_grad_reduce folds them in index order. */
 int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
-                  const float *x, int n, const float *act, const float *heads, const float *g,
+                  const float *x, int n, float *act, const float *heads, const float *g, float *dO_work,
                   float *grads_part, int n_part, int p_stride, void *stream);
 
 /* grads[P] = sum_{g<n_part} grads_part[g][:]  (fixed order). */
@@ -129,11 +132,11 @@ typedef struct ndp_engine {
     float *gpart;                    /* [B][G][p_stride]                                        */
     float *adam_m, *adam_v;          /* [B][p_stride]                                           */
     float *act;                      /* [B][3][n_cap][128]                                      */
-    float *heads;                    /* [B][n_cap][16]                                          */
+    float *heads;                    /* [B][n_cap][NDP_HROW]                                    */
     float *d2x; int *idx_x;          /* [B][n_cap]                                              */
     float *d2y; int *idx_y;          /* [B][t_cap]                                              */
     const float *adam_tab;           /* [iters+1][2]: {neg_step, bc2_sqrt} for t = 1..iters     */
-    float *gbuf;                     /* [B][n_cap][3] dL/d(warped points) of the current tick   */
+    float *dO;                       /* [B][n_cap][16] mlp_scale * dL/d(head outputs), this tick */
 } ndp_engine;
 
 /* Launch n_ticks ticks starting at tick index tick0 (parity selects the state buffer read).
@@ -141,8 +144,8 @@ typedef struct ndp_engine {
  * Asynchronous on `stream`; read state[(tick0 + n_ticks) & 1] after synchronising.              */
 int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream);
 
-/* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[5] (HOST memory)
- * receives the summed durations of the forward, NN, loss/gradient, backward and update kernels over the
+/* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[6] (HOST memory)
+ * receives the summed durations of the forward, NN, loss/gradient, backward-2, backward-1 and update kernels over the
  * n_ticks ticks.  Synchronises `stream`.  Measurement aid for bench.py (roofline), not a product path. */
 int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out);
 

@@ -1,0 +1,157 @@
+"""End-to-end GPU tests of the Registration surface against the reference's own end-to-end goldens.
+Trajectories are chaotic: a 1e-7 perturbation moves final coordinates by up to
+1e-2, so end-to-end agreement is asserted at the level the reference itself reproduces (mean
+coordinate difference, iteration counts within a band, flow metrics), while per-step parity (1e-4)
+is covered by test_hip_parity.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def cfg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from deformationpyramid_amd.config import load_config
+    return load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
+
+
+def test_register_matches_reference_end_to_end_small(cfg, golden):
+    from deformationpyramid_amd.config import Config
+    from deformationpyramid_amd.loss import compute_flow_metrics
+    from deformationpyramid_amd.registration import Registration
+    from deformationpyramid_amd.utils import Timers
+    g = golden("F7_end_to_end")
+    c = Config(cfg, samples=256)
+    torch.manual_seed(0)
+    model = Registration(c)
+    model.load_pcds(g["src"], g["tgt"])
+    timer = Timers()
+    warped, iter_cnt, timer2 = model.register(timer=timer)
+    assert timer2 is timer and "ndp_engine" in timer.timers
+    assert warped.shape == (1024, 3) and warped.is_cuda and not warped.requires_grad
+    assert torch.equal(model.src_pcd.cpu(), torch.from_numpy(g["src"]))            # un-centred source kept
+    counts = np.array([iter_cnt[l] for l in range(9)])
+    ref_counts = g["iters_per_level"]
+    assert counts[0] == ref_counts[0] or abs(int(counts[0]) - int(ref_counts[0])) <= 3, (counts, ref_counts)
+    assert abs(int(counts.sum()) - int(ref_counts.sum())) < 0.5 * ref_counts.sum(), (counts, ref_counts)
+    # the early levels are well conditioned: same evaluation counts as the reference (+-2)
+    assert np.abs(counts[:5].astype(int) - ref_counts[:5].astype(int)).max() <= 2, (counts, ref_counts)
+    diff = np.abs(warped.cpu().numpy() - g["warped"])
+    # Chaos bar: on this 1024-point / 256-sample case the parity-pinned fp32 CPU oracle itself lands
+    # 0.027 (mean) / 0.21 (max) away from the reference after ~240 free-running Adam steps
+    # (later levels take 56 vs 33, 29 vs 80 iterations).  The HIP path must stay in that class.
+    assert diff.mean() < 0.08, diff.mean()
+    m = compute_flow_metrics(warped.cpu() - torch.from_numpy(g["src"]), torch.from_numpy(g["flow_gt"]),
+                             torch.from_numpy(g["overlap"]))
+    ref = dict(zip(g["metric_keys"], g["metric_vals"]))
+    assert abs(m["full-epe"] - ref["full-epe"]) < 0.1 * ref["full-epe"]
+    assert abs(m["vis-epe"] - ref["vis-epe"]) < 0.1 * ref["vis-epe"]
+
+
+def test_register_landmarks_end_to_end(cfg, golden):
+    from deformationpyramid_amd.config import load_config
+    from deformationpyramid_amd.config import Config
+    from deformationpyramid_amd.registration import Registration
+    g = golden("F9b_lndp_end_to_end")
+    c = Config(load_config(os.path.join(ROOT, "config", "LNDP.yaml"), device=0), samples=256)
+    torch.manual_seed(0)
+    model = Registration(c)
+    model.load_pcds(g["src"], g["tgt"], landmarks=(torch.from_numpy(g["ldmk_s"]), torch.from_numpy(g["ldmk_t"])))
+    warped, iter_cnt, _ = model.register()
+    counts = np.array([iter_cnt[l] for l in range(10)])
+    assert abs(int(counts.sum()) - int(g["iters_per_level"].sum())) < 0.5 * g["iters_per_level"].sum()
+    assert abs(model.last_state.loss - g["loss_trace"][-1]) < 0.25 * g["loss_trace"][-1]
+    # the landmark path is well conditioned: the warped cloud agrees closely
+    assert np.abs(warped.cpu().numpy() - g["warped"]).mean() < 5e-3
+    flow_err = np.linalg.norm(warped.cpu().numpy() - g["src"] - g["flow_gt"], axis=1).mean()
+    ref_err = np.linalg.norm(g["warped"] - g["src"] - g["flow_gt"], axis=1).mean()
+    assert abs(flow_err - ref_err) < 0.1 * ref_err + 1e-3
+
+
+def test_register_batch_reproduces_reference_benchmark_metrics(cfg, golden):
+    """F10: the reference's metric rows on 8 synthetic 8192-pt pairs (seed p per pair)."""
+    from deformationpyramid_amd.loss import compute_flow_metrics
+    from deformationpyramid_amd.registration import Registration
+    from deformationpyramid_amd.synthetic import synthetic_pair
+    g = golden("F10_benchmark")
+    keys = list(g["keys"])
+    rows, iters = [], []
+    model = Registration(cfg)
+    for p in range(len(g["seeds"])):
+        src, tgt, flow_gt, overlap = synthetic_pair(p)
+        torch.manual_seed(p)                                   # the fixture seeds per pair
+        model.load_pcds(src.numpy(), tgt.numpy())
+        warped, cnt, _ = model.register()
+        m = compute_flow_metrics(warped.cpu() - src, flow_gt, overlap)
+        rows.append([m[k] for k in keys])
+        iters.append(sum(cnt.values()))
+    rows = np.array(rows)
+    ref = g["rows"]
+    # Calibration of the bar (8 pairs, chaotic trajectories): the parity-pinned CPU oracle gives
+    # full/vis/occ-epe = 15.09 / 11.50 / 25.71 and outlier 85.4 where the reference gives
+    # 14.40 / 10.70 / 25.36 and 82.9 -- i.e. a faithful fp32 restatement already differs by up to 7.5 %
+    # in the 8-pair mean (single pairs by up to 50 %: pair 7 vis-epe 12.96 vs 8.67).
+    for k in ("full-epe", "vis-epe", "occ-epe", "full-outlier"):
+        j = keys.index(k)
+        assert abs(rows[:, j].mean() - ref[:, j].mean()) < 0.12 * ref[:, j].mean(), (k, rows[:, j].mean(), ref[:, j].mean())
+    assert abs(np.mean(iters) - g["iters"].sum(1).mean()) < 0.25 * g["iters"].sum(1).mean()
+
+
+def test_register_batch_equals_sequential_register(cfg):
+    """Same seed, same pairs: the batched path consumes the CPU RNG in the same order as sequential
+    register() calls and lands on the same answer up to trajectory noise; with prefetch on or off the
+    result is bit-identical."""
+    from deformationpyramid_amd.config import Config
+    from deformationpyramid_amd.registration import Registration
+    from deformationpyramid_amd.synthetic import synthetic_pair
+    c = Config(cfg, samples=300, m=3, iters=40)
+    pairs = []
+    for p in range(5):
+        src, tgt, _, _ = synthetic_pair(20 + p, n_total=1500 + 64 * p)
+        pairs.append((src, tgt))
+    torch.manual_seed(3)
+    a = Registration(c).register_batch(pairs, slots=2, prefetch=True)
+    torch.manual_seed(3)
+    b = Registration(c).register_batch(pairs, slots=2, prefetch=False)
+    for (wa, ca), (wb, cb) in zip(a, b):
+        assert torch.equal(wa, wb) and ca == cb
+    torch.manual_seed(3)
+    model = Registration(c)
+    for (src, tgt), (wa, ca) in zip(pairs, a):
+        model.load_pcds(src, tgt)
+        w, cnt, _ = model.register()
+        assert w.shape == wa.shape
+        assert (w - wa).abs().mean().item() < 5e-3
+
+
+def test_autograd_wrappers_drive_a_caller_owned_loop(cfg):
+    """shape_transfer.py style: the caller owns Adam, we supply warp() and the Chamfer loss."""
+    from deformationpyramid_amd.loss import compute_truncated_chamfer_distance
+    from deformationpyramid_amd.nets import Deformation_Pyramid
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    ndp = Deformation_Pyramid(depth=3, width=128, device=dev, k0=-8, m=2, rotation_format="euler", motion="Sim3")
+    g = torch.Generator().manual_seed(2)
+    src = (torch.rand(500, 3, generator=g) - 0.5).to(dev)
+    tgt = (src * 1.1 + 0.05).contiguous()
+    ndp.gradient_setup(optimized_level=0)
+    opt = torch.optim.Adam(ndp.pyramid[0].parameters(), lr=0.01)
+    losses = []
+    for _ in range(15):
+        w, data = ndp.warp(src, max_level=0, min_level=0)
+        loss = compute_truncated_chamfer_distance(w[None], tgt[None], trunc=1e9)
+        losses.append(loss.item())
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    assert losses[-1] < 0.8 * losses[0], losses
+    assert all(p.grad is not None for p in ndp.pyramid[0].parameters())
+    assert all(p.grad is None for p in ndp.pyramid[1].parameters())
+    full, _ = ndp.warp(src)
+    assert full.shape == src.shape

@@ -1,0 +1,27 @@
+"""Fixed small workload for profiling: B synthetic pairs, N ticks at level 0 (all slots active).
+    python tools/tick_bench.py [B] [ticks]"""
+import os, sys, time
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from deformationpyramid_amd.config import load_config
+from deformationpyramid_amd.registration import Registration
+from deformationpyramid_amd.synthetic import synthetic_pair
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 24
+torch.set_num_threads(8)
+dev = torch.device("cuda:0")
+cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
+model = Registration(cfg)
+preps = []
+for i in range(B):
+    s, t, _, _ = synthetic_pair(i)
+    preps.append(model._prepare(s.to(dev), t.to(dev), None))
+eng = model._engine(B, preps[0])
+for b, p in enumerate(preps):
+    eng.load(b, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.store)
+eng.run_ticks(4)
+torch.cuda.synchronize()
+ms = eng.run_ticks_timed(ticks)
+print("B", B, "G", eng.G, "per-tick ms [fwd nn loss bwd2 bwd1 upd]:", [round(x / ticks, 4) for x in ms], "sum", round(sum(ms) / ticks, 4))
