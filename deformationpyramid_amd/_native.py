@@ -123,6 +123,55 @@ def lib(allow_build=True):
     return _LIB
 
 
+# ------------------------------------------------------------------ host runtime library (no GPU)
+HOST_LIBPATH = os.path.join(LIBDIR, "libndp_host.so")
+HOST_SOURCE = os.path.join(CSRC, "ndp_host.cpp")
+_HOST = None
+
+
+class DrawOp(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_longlong), ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("offset", ctypes.c_longlong)]
+
+
+def build_host(force=False):
+    if force or not os.path.exists(HOST_LIBPATH) or os.path.getmtime(HOST_LIBPATH) < os.path.getmtime(HOST_SOURCE):
+        os.makedirs(LIBDIR, exist_ok=True)
+        subprocess.check_call(["g++", "-O3", "-std=c++17", "-ffp-contract=off", "-mfma", "-fPIC", "-shared",
+                               "-o", HOST_LIBPATH, HOST_SOURCE])
+    return HOST_LIBPATH
+
+
+def host_lib():
+    global _HOST
+    if _HOST is None:
+        if not os.path.exists(HOST_LIBPATH) or (os.path.exists(HOST_SOURCE) and shutil.which("g++")
+                                                and os.path.getmtime(HOST_LIBPATH) < os.path.getmtime(HOST_SOURCE)):
+            build_host()
+        L = ctypes.CDLL(HOST_LIBPATH)
+        L.ndp_rng_replay.argtypes = [V, ctypes.c_longlong, ctypes.POINTER(DrawOp), I, I, V, ctypes.c_longlong]
+        L.ndp_rng_replay.restype = I
+        _HOST = L
+    return _HOST
+
+
+def make_draw_ops(ops):
+    return (DrawOp * len(ops))(*[DrawOp(int(n), float(lo), float(hi), int(off)) for n, lo, hi, off in ops])
+
+
+def rng_replay(ops, out):
+    """Run draw ops on torch's global CPU generator (state exported, advanced natively, re-imported)."""
+    import torch
+    if not isinstance(ops, ctypes.Array):
+        ops = make_draw_ops(ops)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.device.type == "cpu"
+    st = torch.get_rng_state()
+    rc = host_lib().ndp_rng_replay(ctypes.c_void_p(st.data_ptr()), st.numel(), ops, len(ops), 1,
+                                   ctypes.c_void_p(out.data_ptr()), 0)
+    if rc != 0:
+        raise NdpError("ndp_rng_replay failed")
+    torch.set_rng_state(st)
+
+
 def check(rc, what):
     if rc != 0:
         msg = lib().ndp_last_error().decode(errors="replace")

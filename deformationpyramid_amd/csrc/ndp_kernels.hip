@@ -32,8 +32,8 @@
 enum : int {
     L_BUFA = 0,
     L_BUFB = L_BUFA + 64 * NDP_LD,
-    L_PE = L_BUFB + 64 * NDP_LD,          // [6][64]
-    L_XS = L_PE + 6 * 64,                 // [64][4] level input x
+    L_PE = L_BUFB + 64 * NDP_LD,          // [64][9] posenc (stride 9: conflict-free MFMA A-operand reads)
+    L_XS = L_PE + 64 * 9,                 // [64][4] level input x
     L_WH = L_XS + 64 * 4,                 // [12][128] head weights (at most 6+1+3+1 = 11 rows)
     L_BH = L_WH + 12 * NDP_W,             // [16]
     L_HO = L_BH + NDP_NHMAX,              // [64][16] head outputs / d_o
@@ -94,6 +94,38 @@ __device__ __forceinline__ void tile_gemm_64x32(const float *in /*LDS [64][LD]*/
     }
 }
 
+// [64][128] tile: LDS (row stride NDP_LD) -> global, 8 float4 per thread, fully coalesced
+__device__ __forceinline__ void store_tile_from_lds(const float *src /*LDS*/, float *dst /*global [64][128]*/) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = t + 256 * i;
+        reinterpret_cast<float4 *>(dst)[idx] = *reinterpret_cast<const float4 *>(src + (idx >> 5) * NDP_LD + 4 * (idx & 31));
+    }
+}
+
+// one quarter (16 k-steps) of tile_gemm_64x32 with a 16-float slice of the lane's weight operand
+__device__ __forceinline__ void tile_gemm_quarter(const float *in /*LDS [64][LD]*/, const float (&w)[16], int q,
+                                                  int l31, int h, f32x16 &acc0, f32x16 &acc1) {
+    const float *r0 = in + l31 * NDP_LD + 64 * h + 16 * q;
+    const float *r1 = r0 + 32 * NDP_LD;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(r0 + 4 * i);
+        const float4 a1 = *reinterpret_cast<const float4 *>(r1 + 4 * i);
+        acc0 = MFMA32(a0.x, w[4 * i], acc0);     acc1 = MFMA32(a1.x, w[4 * i], acc1);
+        acc0 = MFMA32(a0.y, w[4 * i + 1], acc0); acc1 = MFMA32(a1.y, w[4 * i + 1], acc1);
+        acc0 = MFMA32(a0.z, w[4 * i + 2], acc0); acc1 = MFMA32(a1.z, w[4 * i + 2], acc1);
+        acc0 = MFMA32(a0.w, w[4 * i + 3], acc0); acc1 = MFMA32(a1.w, w[4 * i + 3], acc1);
+    }
+}
+// w[i] = W[64h + 16q + i][32wv + l31]: quarter q of the backward (transposed) operand slice, from L2
+__device__ __forceinline__ void load_w_bwd_quarter(const float *W, int q, int wv, int l31, int h, float (&w)[16]) {
+    const float *src = W + (64 * h + 16 * q) * NDP_W + 32 * wv + l31;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = src[i * NDP_W];
+}
+
 // C/D layout of v_mfma_f32_32x32x2_f32: reg r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
 __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -118,82 +150,79 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
     load_w_fwd(W1, wv, l31, h, w1);
     load_w_fwd(W2, wv, l31, h, w2);
     const float bias1 = b1[32 * wv + l31], bias2 = b2[32 * wv + l31];
-    // layer 0: thread (o = t & 127, ph = t >> 7) handles 32 points
-    const int o0 = t & 127, ph = t >> 7;
-    float w0r[6];
+    // layer 0 (6 -> 128) also runs on the matrix pipe: K = 6 = 3 k-steps of the 32x32x2 MFMA
+    float w0b[3];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) w0r[c] = W0[o0 * 6 + c];
-    const float bias0 = b0[o0];
+    for (int ks = 0; ks < 3; ++ks) w0b[ks] = W0[(32 * wv + l31) * 6 + 2 * ks + h];
+    const float bias0 = b0[32 * wv + l31];
     for (int i = t; i < 12 * NDP_W; i += 256) whs[i] = (i < hc.nh * NDP_W) ? Wh[i] : 0.f;
     if (t < NDP_NHMAX) bhs[t] = (t < hc.nh) ? bh[t] : 0.f;
 
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
-        // ---- positional encoding (nets.py:164-177)
-        if (t < 64) {
-            const int p = base + t;
-            float x[3] = {0.f, 0.f, 0.f};
-            if (p < job.n) { x[0] = job.x_in[3 * p]; x[1] = job.x_in[3 * p + 1]; x[2] = job.x_in[3 * p + 2]; }
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const float phs = x[a] * job.freq;
-                pe[(2 * a) * 64 + t] = sinf(phs);
-                pe[(2 * a + 1) * 64 + t] = cosf(phs);
-                xs[4 * t + a] = x[a];
-            }
+        // ---- positional encoding (nets.py:164-177): thread (point = lane, axis = wave) for waves 0..2
+        if (wv < 3) {
+            const int p = base + lane;
+            const float xa = p < job.n ? job.x_in[3 * p + wv] : 0.f;
+            const float phs = xa * job.freq;
+            pe[lane * 9 + 2 * wv] = sinf(phs);
+            pe[lane * 9 + 2 * wv + 1] = cosf(phs);
+            xs[4 * lane + wv] = xa;
         }
         __syncthreads();
-        // ---- layer 0 (6 -> 128, VALU) -> bufA
+        // ---- layer 0 (MFMA, bitwise the k = 0..5 fmaf chain starting from the bias) -> bufA
         {
-            float *a0g = job.act ? job.act + (size_t)base * NDP_W : nullptr;
-#pragma unroll 4
-            for (int pp = 0; pp < 32; ++pp) {
-                const int p = 32 * ph + pp;
-                float acc = bias0;
+            f32x16 acc0, acc1;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) acc = fmaf(w0r[c], pe[c * 64 + p], acc);
-                acc = acc > 0.f ? acc : 0.f;
-                bufA[p * NDP_LD + o0] = acc;
-                if (a0g) a0g[p * NDP_W + o0] = acc;
+            for (int r = 0; r < 16; ++r) { acc0[r] = bias0; acc1[r] = bias0; }
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const float a0 = pe[l31 * 9 + 2 * ks + h], a1 = pe[(l31 + 32) * 9 + 2 * ks + h];
+                acc0 = MFMA32(a0, w0b[ks], acc0);
+                acc1 = MFMA32(a1, w0b[ks], acc1);
+            }
+            const int col = 32 * wv + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, h);
+                bufA[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
+                bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
             }
         }
         __syncthreads();
-        // ---- layer 1 (MFMA) bufA -> bufB
+        // ---- layer 1 (MFMA) bufA -> bufB ; h0 goes to HBM as float4 rows while the matrix pipe works
         {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = bias1; acc1[r] = bias1; }
+            if (job.act) store_tile_from_lds(bufA, job.act + (size_t)base * NDP_W);
             tile_gemm_64x32(bufA, w1, l31, h, acc0, acc1);
-            float *a1g = job.act ? job.act + ((size_t)job.plane + base) * NDP_W : nullptr;
             const int col = 32 * wv + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, h);
-                const float v0 = acc0[r] > 0.f ? acc0[r] : 0.f, v1 = acc1[r] > 0.f ? acc1[r] : 0.f;
-                bufB[row * NDP_LD + col] = v0;
-                bufB[(row + 32) * NDP_LD + col] = v1;
-                if (a1g) { a1g[row * NDP_W + col] = v0; a1g[(row + 32) * NDP_W + col] = v1; }
+                bufB[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
+                bufB[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
             }
         }
         __syncthreads();
-        // ---- layer 2 (MFMA) bufB -> bufA
+        // ---- layer 2 (MFMA) bufB -> bufA ; h1 -> HBM
         {
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = bias2; acc1[r] = bias2; }
+            if (job.act) store_tile_from_lds(bufB, job.act + ((size_t)job.plane + base) * NDP_W);
             tile_gemm_64x32(bufB, w2, l31, h, acc0, acc1);
-            float *a2g = job.act ? job.act + (2 * (size_t)job.plane + base) * NDP_W : nullptr;
             const int col = 32 * wv + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, h);
-                const float v0 = acc0[r] > 0.f ? acc0[r] : 0.f, v1 = acc1[r] > 0.f ? acc1[r] : 0.f;
-                bufA[row * NDP_LD + col] = v0;
-                bufA[(row + 32) * NDP_LD + col] = v1;
-                if (a2g) { a2g[row * NDP_W + col] = v0; a2g[(row + 32) * NDP_W + col] = v1; }
+                bufA[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
+                bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
             }
         }
         __syncthreads();
+        if (job.act) store_tile_from_lds(bufA, job.act + (2 * (size_t)job.plane + base) * NDP_W);   // h2 -> HBM
         // ---- heads (nets.py:117,125,146): thread (p = lane, jq = wave) computes heads jq, jq+4, ...
         {
             const float *hrow = bufA + lane * NDP_LD;
@@ -222,8 +251,9 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
 #pragma unroll
                 for (int j = 0; j < NDP_NHMAX; j += 4)
                     *reinterpret_cast<float4 *>(hr + j) = *reinterpret_cast<const float4 *>(o + j);
-                *reinterpret_cast<float4 *>(hr + 16) = make_float4(pe[t], pe[64 + t], pe[128 + t], pe[192 + t]);
-                *reinterpret_cast<float4 *>(hr + 20) = make_float4(pe[256 + t], pe[320 + t], 0.f, 0.f);
+                const float *pr = pe + t * 9;
+                *reinterpret_cast<float4 *>(hr + 16) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+                *reinterpret_cast<float4 *>(hr + 20) = make_float4(pr[4], pr[5], 0.f, 0.f);
             }
             if (p < job.n) {
                 PointHead c;
@@ -248,8 +278,8 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
 enum : int {
     LB_BUFA = 0,
     LB_BUFB = LB_BUFA + 64 * NDP_LD,
-    LB_DO = LB_BUFB + 64 * NDP_LD,        // [64][16]
-    LB_PE = LB_DO + 64 * NDP_NHMAX,       // [6][64]
+    LB_DO = LB_BUFB + 64 * NDP_LD,        // [64][17] (stride 17: conflict-free MFMA A-operand reads)
+    LB_PE = LB_DO + 64 * 17,              // [6][64]
     LB_TOTAL = LB_PE + 6 * 64
 };
 static constexpr int kSmemBwdBytes = LB_TOTAL * 4;       // 73.2 KB: two workgroups per CU
@@ -279,7 +309,7 @@ __device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] gl
 // dW[mt] += dz^T h   (rows o = 32*mt.., cols k = 32wv + l31), contraction over the tile's 64 points
 __device__ __forceinline__ void tile_outer_128x32(const float *dz /*LDS [64][LD]*/, const float *hin /*LDS [64][LD]*/,
                                                   int wv, int l31, int h, f32x16 (&dW)[4]) {
-#pragma unroll 8
+#pragma unroll 2
     for (int ks = 0; ks < 32; ++ks) {
         const int p = 32 * h + ks;
         const float b = hin[p * NDP_LD + 32 * wv + l31];
@@ -300,12 +330,76 @@ __device__ __forceinline__ void store_dW(float *g, const f32x16 (&dW)[4], int wv
         for (int r = 0; r < 16; ++r) g[(32 * m + mfma_row(r, h)) * NDP_W + col] = dW[m][r];
 }
 
+// head stage of the backward: dz2 = (dO Wh) * [h2 > 0] written over the h2 plane ; dWh += dO^T h2 ; dbh
+// Light in registers (two MFMA accumulator pairs + 8 weight floats) -> many workgroups per CU.
+__device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *bufA = sm, *dOs = sm + 64 * NDP_LD;
+    const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
+    const float *Wh = job.params + ndp_off_Wi(&dd, 3);
+    // head matrix as an MFMA B operand: whb[ks] = Wh[j = 2ks + h][k = 32wv + l31], K = 16 head slots
+    float whb[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) whb[ks] = (2 * ks + h) < hc.nh ? Wh[(2 * ks + h) * NDP_W + 32 * wv + l31] : 0.f;
+    f32x16 gWh;                                 // dWh[j][k]: rows j = mfma_row(r, h) (< 16 used), cols 32wv + l31
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gWh[r] = 0.f;
+    float gbh = 0.f;
+    for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
+        const int base = tile * NDP_TILE;
+        float *plane2 = job.act + (2 * (size_t)job.plane + base) * NDP_W;
+        {
+            const float4 dv = reinterpret_cast<const float4 *>(job.dO + (size_t)base * NDP_NHMAX)[t];
+            load_tile_to_lds(plane2, bufA);
+            float *dr = dOs + (t >> 2) * 17 + 4 * (t & 3);
+            dr[0] = dv.x; dr[1] = dv.y; dr[2] = dv.z; dr[3] = dv.w;
+        }
+        __syncthreads();
+        {
+            f32x16 a0, a1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float A0 = dOs[l31 * 17 + 2 * ks + h], A1 = dOs[(l31 + 32) * 17 + 2 * ks + h];
+                a0 = MFMA32(A0, whb[ks], a0);
+                a1 = MFMA32(A1, whb[ks], a1);
+            }
+#pragma unroll 4
+            for (int ks = 0; ks < 32; ++ks) {
+                const int p = 32 * h + ks;
+                const float A = l31 < NDP_NHMAX ? dOs[p * 17 + l31] : 0.f;
+                gWh = MFMA32(A, bufA[p * NDP_LD + 32 * wv + l31], gWh);
+            }
+            const int col = 32 * wv + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma_row(r, h);
+                plane2[row * NDP_W + col] = bufA[row * NDP_LD + col] > 0.f ? a0[r] : 0.f;
+                plane2[(row + 32) * NDP_W + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? a1[r] : 0.f;
+            }
+            if (t < NDP_NHMAX) {
+                for (int p = 0; p < 64; ++p) gbh += dOs[p * 17 + t];
+            }
+        }
+        __syncthreads();
+    }
+    float *gwh = job.gpart + ndp_off_Wi(&dd, 3);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int j = mfma_row(r, h);
+        if (j < hc.nh) gwh[j * NDP_W + 32 * wv + l31] = gWh[r];
+    }
+    if (t < hc.nh) gwh[hc.nh * NDP_W + t] = gbh;
+}
+static constexpr int kSmemBwdHBytes = (64 * NDP_LD + 64 * 17) * 4;      // 38 KB
+
+// hidden layer 2: dW2 += dz2^T h1 ; db2 ; dh1 = dz2 W2 ; dz1 = dh1 * [h1 > 0] written over dz2 (plane 2)
 __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
-    float *bufA = sm + LB_BUFA, *bufB = sm + LB_BUFB, *dOs = sm + LB_DO;
+    float *bufA = sm + LB_BUFA, *bufB = sm + LB_BUFB;
     const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
-    const float *P = job.params;
-    const float *W2 = P + ndp_off_Wi(&dd, 2), *Wh = P + ndp_off_Wi(&dd, 3);
+    const float *W2 = job.params + ndp_off_Wi(&dd, 2);
     float w2t[64];
     load_w_bwd(W2, wv, l31, h, w2t);
     f32x16 dW2[4];
@@ -313,48 +407,14 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dW2[m][r] = 0.f;
-    const int o0 = t & 127, ph = t >> 7;      // VALU phases: thread (column o0, point half ph)
-    float whk[NDP_NHP], gWh[NDP_NHP];
-#pragma unroll
-    for (int j = 0; j < NDP_NHP; ++j) { whk[j] = j < hc.nh ? Wh[j * NDP_W + o0] : 0.f; gWh[j] = 0.f; }
-    float gb2 = 0.f, gbh = 0.f;
-
+    const int o0 = t & 127, ph = t >> 7;
+    float gb2 = 0.f;
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
-        // ---- dO tile and h2 tile
-        {
-            const float4 dv = reinterpret_cast<const float4 *>(job.dO + (size_t)base * NDP_NHMAX)[t];
-            load_tile_to_lds(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufA);
-            *reinterpret_cast<float4 *>(dOs + 4 * t) = dv;
-        }
+        float *plane2 = job.act + (2 * (size_t)job.plane + base) * NDP_W;
+        load_tile_to_lds(plane2, bufB);                                            // dz2
+        load_tile_to_lds(job.act + ((size_t)job.plane + base) * NDP_W, bufA);      // h1
         __syncthreads();
-        // ---- dh2 = dO . Wh ; dz2 = dh2 * [h2 > 0] -> bufB ; head-weight gradients
-        {
-#pragma unroll 2
-            for (int pp = 0; pp < 32; ++pp) {
-                const int p = 32 * ph + pp;
-                const float hv = bufA[p * NDP_LD + o0];
-                const float *dor = dOs + p * NDP_NHMAX;
-                float dh = 0.f;
-#pragma unroll
-                for (int j4 = 0; j4 < NDP_NHP; j4 += 4) {
-                    const float4 d4 = *reinterpret_cast<const float4 *>(dor + j4);
-                    dh = fmaf(d4.x, whk[j4], dh);         gWh[j4] = fmaf(d4.x, hv, gWh[j4]);
-                    dh = fmaf(d4.y, whk[j4 + 1], dh);     gWh[j4 + 1] = fmaf(d4.y, hv, gWh[j4 + 1]);
-                    dh = fmaf(d4.z, whk[j4 + 2], dh);     gWh[j4 + 2] = fmaf(d4.z, hv, gWh[j4 + 2]);
-                    dh = fmaf(d4.w, whk[j4 + 3], dh);     gWh[j4 + 3] = fmaf(d4.w, hv, gWh[j4 + 3]);
-                }
-                bufB[p * NDP_LD + o0] = hv > 0.f ? dh : 0.f;
-            }
-            if (t < NDP_NHMAX) {
-                for (int p = 0; p < 64; ++p) gbh += dOs[p * NDP_NHMAX + t];
-            }
-        }
-        __syncthreads();
-        // ---- h1 tile -> bufA
-        load_tile_to_lds(job.act + ((size_t)job.plane + base) * NDP_W, bufA);
-        __syncthreads();
-        // ---- dW2 += dz2^T h1 ; dh1 = dz2 W2 ; db2 ; dz1 = dh1 * [h1 > 0] -> global (over the h2 plane)
         {
             f32x16 d0, d1;
 #pragma unroll
@@ -363,37 +423,27 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
             tile_gemm_64x32(bufB, w2t, l31, h, d0, d1);
 #pragma unroll 8
             for (int pp = 0; pp < 32; ++pp) gb2 += bufB[(32 * ph + pp) * NDP_LD + o0];
-            float *dz1 = job.act + (2 * (size_t)job.plane + base) * NDP_W;
+            __syncthreads();                       // every wave is done reading dz2
+            // dz1 goes through LDS so that HBM sees coalesced float4 rows (and the epilogue needs one base
+            // address instead of 32 per-element addresses, which used to cost 58 spilled registers)
             const int col = 32 * wv + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, h);
-                dz1[row * NDP_W + col] = bufA[row * NDP_LD + col] > 0.f ? d0[r] : 0.f;
-                dz1[(row + 32) * NDP_W + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? d1[r] : 0.f;
+                bufB[row * NDP_LD + col] = bufA[row * NDP_LD + col] > 0.f ? d0[r] : 0.f;
+                bufB[(row + 32) * NDP_LD + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? d1[r] : 0.f;
             }
         }
         __syncthreads();
+        store_tile_from_lds(bufB, plane2);
+        __syncthreads();
     }
-    // ---- epilogue: this workgroup's partial of W2, b2, Wh, bh
     float *G = job.gpart;
     store_dW(G + ndp_off_Wi(&dd, 2), dW2, wv, l31, h);
     float *sc = sm + LB_BUFA;
-    if (ph == 1) {
-        float *s = sc + o0 * 16;
-        s[0] = gb2;
-#pragma unroll
-        for (int j = 0; j < NDP_NHP; ++j) s[1 + j] = gWh[j];
-    }
+    if (ph == 1) sc[o0] = gb2;
     __syncthreads();
-    if (ph == 0) {
-        const float *s = sc + o0 * 16;
-        G[ndp_off_bi(&dd, 2) + o0] = gb2 + s[0];
-        float *gwh = G + ndp_off_Wi(&dd, 3);
-#pragma unroll
-        for (int j = 0; j < NDP_NHP; ++j)
-            if (j < hc.nh) gwh[j * NDP_W + o0] = gWh[j] + s[1 + j];
-        if (t < hc.nh) gwh[hc.nh * NDP_W + t] = gbh;
-    }
+    if (ph == 0) G[ndp_off_bi(&dd, 2) + o0] = gb2 + sc[o0];
 }
 
 __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
@@ -503,6 +553,15 @@ k_level_bwd2(HeadCfg hc, BwdJob job, int p_stride) {
     job.tile_step = gridDim.x;
     job.gpart += (size_t)blockIdx.x * p_stride;
     bwd2_body(hc, job, sm);
+}
+
+extern "C" __global__ void __launch_bounds__(256, 4)
+k_level_bwdh(HeadCfg hc, BwdJob job, int p_stride) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    job.tile0 = blockIdx.x;
+    job.tile_step = gridDim.x;
+    job.gpart += (size_t)blockIdx.x * p_stride;
+    bwdh_body(hc, job, sm);
 }
 
 extern "C" __global__ void __launch_bounds__(256, 2)
@@ -963,11 +1022,19 @@ __device__ __forceinline__ bool eng_bwd_job(const ndp_engine &e, int parity, Bwd
     return true;
 }
 
+extern "C" __global__ void __launch_bounds__(256, 4)
+k_eng_bwdh(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    BwdJob job;
+    if (!eng_bwd_job(e, parity, job, true)) return;
+    bwdh_body(make_head_cfg(e.desc), job, sm);
+}
+
 extern "C" __global__ void __launch_bounds__(256, 2)
 k_eng_bwd2(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
-    if (!eng_bwd_job(e, parity, job, true)) return;
+    if (!eng_bwd_job(e, parity, job, false)) return;
     bwd2_body(make_head_cfg(e.desc), job, sm);
 }
 
@@ -1083,9 +1150,11 @@ extern "C" int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, in
         n_part = job.n_tiles;
     }
     if (int rc = set_smem((const void *)k_level_bwd2, kSmemBwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_level_bwdh, kSmemBwdHBytes)) return rc;
     if (int rc = set_smem((const void *)k_level_bwd1, kSmemBwdBytes)) return rc;
     const HeadCfg hc = make_head_cfg(*desc);
     hipLaunchKernelGGL(k_head_bwd, dim3((job.plane + 255) / 256), dim3(256), 0, s, hc, x, heads, g, n, job.plane, dO_work);
+    hipLaunchKernelGGL(k_level_bwdh, dim3(n_part), dim3(256), kSmemBwdHBytes, s, hc, job, p_stride);
     hipLaunchKernelGGL(k_level_bwd2, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
     hipLaunchKernelGGL(k_level_bwd1, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
     HIP_TRY(hipGetLastError(), "level backward launch");
@@ -1162,6 +1231,7 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
         return fail(NDP_E_INVALID, "ndp_engine_run: null buffer");
     if (int rc = set_smem((const void *)k_eng_fwd, kSmemFwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_eng_bwdh, kSmemBwdHBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const dim3 blk(256);
@@ -1174,6 +1244,7 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
         hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         if (e->w_cd != 0.f && e->d2x) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
         hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_bwdh, g_lvl, blk, kSmemBwdHBytes, s, *e, parity);
         hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
@@ -1183,13 +1254,14 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
 }
 
 // Profiling variant of ndp_engine_run: HIP events around every kernel of every tick, recorded on the
-// launch stream; ms_out[6] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwd2, k_eng_bwd1, k_eng_update.
+// launch stream; ms_out[6] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwdh + k_eng_bwd2, k_eng_bwd1, k_eng_update.
 // Synchronises the stream before returning.  Used by bench.py for the roofline figures only.
 extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out) {
     if (!e || !ms_out || n_ticks < 1 || n_ticks > 4096) return fail(NDP_E_INVALID, "ndp_engine_run_timed: bad arguments");
     if (int rc = check_desc(&e->desc)) return rc;
     if (int rc = set_smem((const void *)k_eng_fwd, kSmemFwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_eng_bwdh, kSmemBwdHBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const dim3 blk(256);
@@ -1211,6 +1283,7 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
         (void)hipEventRecord(q[2], s);
         hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         (void)hipEventRecord(q[3], s);
+        hipLaunchKernelGGL(k_eng_bwdh, g_lvl, blk, kSmemBwdHBytes, s, *e, parity);
         hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         (void)hipEventRecord(q[4], s);
         hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);

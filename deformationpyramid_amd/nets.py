@@ -56,11 +56,73 @@ def _init_level_flat(desc: LayerDesc, depth: int, out: torch.Tensor = None) -> t
     return flat
 
 
-def init_pyramid_store(descs, depth, p_stride):
+def _draw_ops(descs, depth, p_stride):
+    """The reference's RNG consumption as a flat list of (count, lo, hi, offset) draw ops over the
+    [m, p_stride] store; offset -1 = values the reference overwrites later (only advance the generator)."""
+    ops = []
+    for lvl, d in enumerate(descs):
+        assert depth - 1 == d.n_hidden
+        base = lvl * p_stride
+        slices = d.named_slices()
+        xav = []
+        for (wname, woff, wshape), (bname, boff, bshape) in zip(slices[0::2], slices[1::2]):
+            fan_out, fan_in = wshape
+            ops.append((fan_out * fan_in, 0.0, 1.0, -1))                  # kaiming_uniform_ draw, overwritten by xavier
+            bb = 1 / math.sqrt(fan_in)
+            ops.append((fan_out, -bb, bb, base + boff))                   # nn.Linear bias init
+            a = math.sqrt(3.0) * (1.0 * math.sqrt(2.0 / float(fan_in + fan_out)))
+            xav.append((fan_out * fan_in, -a, a, base + woff))            # xavier_uniform_
+        ops += xav
+    return ops
+
+
+_NATIVE_RNG = {"checked": False, "ok": False}
+
+
+def _native_rng_ok():
+    """One-time self check of the native generator replay against torch itself (same draws, same bits,
+    same generator state afterwards).  If it ever disagrees the torch-call replay is used instead."""
+    if not _NATIVE_RNG["checked"]:
+        _NATIVE_RNG["checked"] = True
+        try:
+            from . import _native as N
+            saved = torch.get_rng_state()
+            torch.manual_seed(987654321)
+            a = torch.empty(700).uniform_(-1.5, -0.25)
+            torch.empty(333).uniform_(0.0, 1.0)
+            b = torch.empty(1300).uniform_(-0.0883883461356163, 0.0883883461356163)
+            r1 = torch.randperm(17)
+            torch.manual_seed(987654321)
+            out = torch.zeros(2000)
+            N.rng_replay([(700, -1.5, -0.25, 0), (333, 0.0, 1.0, -1), (1300, -0.0883883461356163, 0.0883883461356163, 700)],
+                         out)
+            r2 = torch.randperm(17)
+            _NATIVE_RNG["ok"] = bool(torch.equal(out[:700], a) and torch.equal(out[700:], b) and torch.equal(r1, r2))
+            torch.set_rng_state(saved)
+        except Exception:
+            _NATIVE_RNG["ok"] = False
+    return _NATIVE_RNG["ok"]
+
+
+_OPS_CACHE = {}
+
+
+def init_pyramid_store(descs, depth, p_stride, native=True):
     """[m, p_stride] CPU tensor with every level initialised in order (the RNG replay of
     Deformation_Pyramid.__init__, nets.py:20-30) -- the part of the constructor the batched
-    registration path needs, without the per-name Parameter views."""
+    registration path needs, without the per-name Parameter views.  With native=True the draws
+    are produced by libndp_host.so (bit-identical to torch's generator, ~4x faster)."""
+    descs = list(descs)
     store = torch.empty(len(descs), p_stride, dtype=torch.float32)
+    if native and _native_rng_ok():
+        from . import _native as N
+        key = (tuple(descs), depth, p_stride)
+        if key not in _OPS_CACHE:
+            _OPS_CACHE[key] = N.make_draw_ops(_draw_ops(descs, depth, p_stride))
+        for i, d in enumerate(descs):
+            store[i, d.param_count:] = 0.0
+        N.rng_replay(_OPS_CACHE[key], store)
+        return store
     with torch.no_grad():
         for i, d in enumerate(descs):
             _init_level_flat(d, depth, out=store[i, :d.param_count])

@@ -138,3 +138,31 @@ def test_two_rank_gloo_aggregation():
                           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "tests", "_gloo_worker.py")],
                          capture_output=True, text=True, env=env, timeout=240)
     assert "AGG_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_native_rng_replay_matches_torch():
+    """libndp_host.so reproduces torch's CPU generator bit for bit (values and the state torch continues
+    from), for the init replay of a whole pyramid and for mixed draw/discard sequences."""
+    from deformationpyramid_amd import _native
+    from deformationpyramid_amd.layout import LayerDesc
+    from deformationpyramid_amd.nets import init_pyramid_store, _native_rng_ok
+    assert _native_rng_ok()
+    for descs in ([LayerDesc()] * 9, [LayerDesc(motion="Sim3", rotfmt="euler")] * 3,
+                  [LayerDesc(rotfmt="quaternion"), LayerDesc(rotfmt="quaternion", nonrigidity=True)]):
+        stride = (max(d.param_count for d in descs) + 63) // 64 * 64
+        torch.manual_seed(5)
+        a = init_pyramid_store(descs, 3, stride, native=False)
+        ra = torch.randperm(1000)
+        torch.manual_seed(5)
+        b = init_pyramid_store(descs, 3, stride, native=True)
+        rb = torch.randperm(1000)
+        assert torch.equal(a, b) and torch.equal(ra, rb)
+    # generator positions around the 624-word block boundary
+    for skip in (0, 1, 622, 623, 624, 625, 1247):
+        torch.manual_seed(11)
+        torch.empty(skip).uniform_() if skip else None
+        x = torch.empty(700).uniform_(-0.25, 1.75)
+        torch.manual_seed(11)
+        out = torch.zeros(700)
+        _native.rng_replay([(skip, 0.0, 1.0, -1), (700, -0.25, 1.75, 0)] if skip else [(700, -0.25, 1.75, 0)], out)
+        assert torch.equal(out, x), skip
