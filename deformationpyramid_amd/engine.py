@@ -73,6 +73,8 @@ class BatchedEngine:
         self.geom = torch.zeros(B, 4, device=d, dtype=torch.int32)
         self._geom_h = np.zeros((B, 4), dtype=np.int32)
         self._state_h = torch.zeros(B, self.state_nbytes, dtype=torch.uint8).pin_memory()
+        self._snap = [torch.zeros(B, self.state_nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
+        self._snap_i = 0
         self.tick = 0
         self._mk_struct()
 
@@ -138,6 +140,23 @@ class BatchedEngine:
         self._state_h.copy_(self.state[self.tick & 1], non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         raw = self._state_h.numpy().tobytes()
+        sz = self.state_nbytes
+        return [N.PairState.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(self.B)]
+
+    def snapshot_async(self):
+        """Enqueue a device->host copy of the current pair states; returns a handle for wait_snapshot().
+        Two pinned buffers alternate, so at most one snapshot may be outstanding besides the newest."""
+        buf = self._snap[self._snap_i]
+        self._snap_i ^= 1
+        buf.copy_(self.state[self.tick & 1], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        return ev, buf
+
+    def wait_snapshot(self, handle):
+        ev, buf = handle
+        ev.synchronize()
+        raw = buf.numpy().tobytes()
         sz = self.state_nbytes
         return [N.PairState.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(self.B)]
 

@@ -79,7 +79,7 @@ class Registration:
         return warped, iter_cnt, timer
 
     # ------------------------------------------------------------------ batched extension
-    def register_batch(self, pairs, slots=64, chunk=16, prefetch=True):
+    def register_batch(self, pairs, slots=64, chunk=8, prefetch=True):
         """pairs: sequence of (src, tgt) or (src, tgt, (ldmk_s, ldmk_t)).  Pairs are prepared in order
         (so the CPU RNG stream is consumed exactly as by sequential register() calls) and optimised
         `slots` at a time, finished slots being refilled.  With prefetch=True the host-side preparation
@@ -142,9 +142,13 @@ class Registration:
         eng = self._engine(B, first[1], n_hint=self.config.samples + (first[1].K if first[1].K else 0))
         for slot in range(B):
             eng.park(slot)
-        active, free, exhausted = {}, list(range(B)), False
+        # Pipelined control loop: the states of chunk k are read back while chunk k+1 runs, so the GPU
+        # never waits for the host; a slot that finishes in chunk k is refilled before chunk k+2.
+        active, free, exhausted = {}, list(range(B)), False      # active: slot -> (pair index, first valid snapshot)
         nxt = first
         m = self.config.m
+        seq = 0                                                  # snapshots taken so far
+        pending = None
         while True:
             while free and not exhausted:
                 if nxt is None:
@@ -156,21 +160,29 @@ class Registration:
                 nxt = None
                 slot = free.pop()
                 eng.load(slot, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.store)
-                active[slot] = i
-            if not active:
+                active[slot] = (i, seq)                          # snapshots >= seq see this pair in the slot
+            if not active and pending is None:
                 break
-            eng.run_ticks(chunk)
-            states = eng.read_states()
-            for slot in list(active):
-                st = states[slot]
-                if st.level < m:
-                    continue
-                i = active.pop(slot)
-                p = preps[i]
-                p.result = self._finish(eng, slot, p, st)
-                p.state = st
-                eng.park(slot)
-                free.append(slot)
+            handle = None
+            if active:
+                eng.run_ticks(chunk)
+                handle = (eng.snapshot_async(), seq)
+                seq += 1
+            if pending is not None:
+                (h, hseq) = pending
+                states = eng.wait_snapshot(h)
+                for slot in list(active):
+                    i, valid_from = active[slot]
+                    st = states[slot]
+                    if hseq < valid_from or st.level < m:
+                        continue
+                    del active[slot]
+                    p = preps[i]
+                    p.result = self._finish(eng, slot, p, st)
+                    p.state = st
+                    eng.park(slot)
+                    free.append(slot)
+            pending = handle
         self.last_states = [p.state for p in preps]
         return [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
 
