@@ -847,12 +847,12 @@ k_eng_nn(ndp_engine e, int parity) {
 //   every workgroup : the gradient of the loss wrt its 256 warped points -- own nearest-neighbour
 //                     term, then the targets whose nearest source point it is, in ascending target
 //                     index (the order a sequential CPU scatter-add produces), no atomics.
-#define LG_CHUNK 2048
+#define LG_CHUNK 8192
 extern "C" __global__ void __launch_bounds__(256)
 k_eng_loss(ndp_engine e, int parity) {
     __shared__ float red[256];
-    __shared__ __attribute__((aligned(16))) int iys[LG_CHUNK];
-    __shared__ __attribute__((aligned(16))) float tys[LG_CHUNK * 4];     // (x, y, z, d2y) of the staged targets
+    __shared__ int cnt[256], start[256];                                  // per-point bucket sizes / offsets
+    __shared__ int order[LG_CHUNK];                                       // targets grouped by their nearest source point
     __shared__ __attribute__((aligned(16))) float rows[256 * NDP_NHMAX];  // per-thread head rows
     const int b = blockIdx.y, t = threadIdx.x;
     const ndp_pair_state st = e.state[parity * e.B + b];
@@ -906,7 +906,6 @@ k_eng_loss(ndp_engine e, int parity) {
                 c.break_counter = bc;
                 c.loss_prev = lp;
             } else {                                       // registration.py:242-249 + :179-180
-                c.evals_per_level[st.level] = st.iter + 1;
                 c.level = st.level + 1;
                 c.iter = 0;
                 c.adam_t = 0;
@@ -915,6 +914,8 @@ k_eng_loss(ndp_engine e, int parity) {
                 c.cur = st.cur ^ 1;
             }
             *nst = c;
+            // (written straight to memory: a run-time index into the private copy would push it to scratch)
+            if (decision != NDP_DEC_STEP) nst->evals_per_level[st.level] = st.iter + 1;
         }
     }
     // ---- gradient of the loss wrt the warped points of this workgroup
@@ -938,49 +939,75 @@ k_eng_loss(ndp_engine e, int parity) {
         }
     }
     if (use_cd && blockIdx.x * 256 + 255 >= gm.K) {  // workgroup holds at least one sample
+        // Targets whose nearest source point belongs to this workgroup, grouped per point by a counting
+        // sort in LDS (O(T) per workgroup instead of a T-long scan per point), each group then sorted so
+        // that the contributions are added in ascending target index -- the order of a sequential CPU
+        // scatter-add, hence bit-identical to the oracle -- without any float atomics.
         const bool live = p >= gm.K && p < n;
+        const int i_lo = (int)blockIdx.x * 256 - gm.K;                   // sample index of thread 0
         for (int c0 = 0; c0 < gm.T; c0 += LG_CHUNK) {
+            const int cn = min(LG_CHUNK, gm.T - c0);
             __syncthreads();
-            {   // all loads first, then the LDS stores: one exposed memory latency per chunk
-                int iv[LG_CHUNK / 256];
-                float4 tv[LG_CHUNK / 256];
+            cnt[t] = 0;
+            __syncthreads();
+            // pass 1: count (targets are re-read in pass 2 rather than kept in a register array)
+            for (int k0 = 0; k0 < LG_CHUNK / 256; k0 += 8) {
+                int li[8];
 #pragma unroll
-                for (int k = 0; k < LG_CHUNK / 256; ++k) {
-                    const int j = t + 256 * k;
-                    iv[k] = -1;
-                    tv[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (c0 + j < gm.T) {
-                        const float *tp = tgt + 3 * (size_t)(c0 + j);
-                        iv[k] = idx_y[c0 + j];
-                        tv[k] = make_float4(tp[0], tp[1], tp[2], d2y[c0 + j]);
-                    }
+                for (int k = 0; k < 8; ++k) {
+                    const int j = t + 256 * (k0 + k);
+                    li[k] = j < cn ? idx_y[c0 + j] - i_lo : -1;
                 }
 #pragma unroll
-                for (int k = 0; k < LG_CHUNK / 256; ++k) {
-                    const int j = t + 256 * k;
-                    iys[j] = iv[k];
-                    *reinterpret_cast<float4 *>(tys + 4 * j) = tv[k];
-                }
+                for (int k = 0; k < 8; ++k)
+                    if (li[k] >= 0 && li[k] < 256) atomicAdd(&cnt[li[k]], 1);
+                if (256 * (k0 + 8) >= cn) break;
             }
             __syncthreads();
-            const int cn = min(LG_CHUNK, gm.T - c0);
-            const int key = live ? i_self : -2;       // -2 never matches (padding is -1)
-#pragma unroll 4
-            for (int j4 = 0; j4 < (cn + 3) / 4; ++j4) {
-                const int4 v = *reinterpret_cast<const int4 *>(iys + 4 * j4);
-                if ((v.x == key) | (v.y == key) | (v.z == key) | (v.w == key)) {      // rare: ~1 hit per point
-                    const int vv[4] = {v.x, v.y, v.z, v.w};
+            // exclusive scan of cnt -> start (Hillis-Steele over 256 entries)
+            const int mine = cnt[t];
+            start[t] = mine;
+            __syncthreads();
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (vv[q] == key) {
-                            const float4 tv = *reinterpret_cast<const float4 *>(tys + 4 * (4 * j4 + q));
-                            if (!(tv.w >= e.trunc)) {
-                                const float inv = 1.0f / ((float)gm.T * sqrtf(tv.w));
-                                g[0] = fmaf(w[0] - tv.x, inv, g[0]);
-                                g[1] = fmaf(w[1] - tv.y, inv, g[1]);
-                                g[2] = fmaf(w[2] - tv.z, inv, g[2]);
-                            }
-                        }
+            for (int d = 1; d < 256; d <<= 1) {
+                const int v = t >= d ? start[t - d] : 0;
+                __syncthreads();
+                start[t] += v;
+                __syncthreads();
+            }
+            const int my_start = start[t] - mine;
+            __syncthreads();
+            start[t] = my_start;                                          // becomes the fill cursor
+            __syncthreads();
+            for (int k0 = 0; k0 < LG_CHUNK / 256; k0 += 8) {
+                int li[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int j = t + 256 * (k0 + k);
+                    li[k] = j < cn ? idx_y[c0 + j] - i_lo : -1;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (li[k] >= 0 && li[k] < 256) order[atomicAdd(&start[li[k]], 1)] = c0 + t + 256 * (k0 + k);
+                if (256 * (k0 + 8) >= cn) break;
+            }
+            __syncthreads();
+            if (live && mine > 0) {
+                int *bk = order + my_start;                               // this thread's private range
+                for (int a = 1; a < mine; ++a) {                          // insertion sort, ascending target index
+                    const int v = bk[a];
+                    int q = a - 1;
+                    while (q >= 0 && bk[q] > v) { bk[q + 1] = bk[q]; --q; }
+                    bk[q + 1] = v;
+                }
+                for (int a = 0; a < mine; ++a) {
+                    const int j = bk[a];
+                    const float d2 = d2y[j];
+                    if (!(d2 >= e.trunc)) {
+                        const float inv = 1.0f / ((float)gm.T * sqrtf(d2));
+                        g[0] = fmaf(w[0] - tgt[3 * j], inv, g[0]);
+                        g[1] = fmaf(w[1] - tgt[3 * j + 1], inv, g[1]);
+                        g[2] = fmaf(w[2] - tgt[3 * j + 2], inv, g[2]);
                     }
                 }
             }

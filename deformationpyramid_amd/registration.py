@@ -92,6 +92,7 @@ class Registration:
         preps = [None] * len(pairs)
         dev = self._dev()
         side = torch.cuda.Stream(dev) if prefetch else None
+        fin_stream = torch.cuda.Stream(dev)                      # final all-point warps overlap the ticking engine
 
         def produce():
             try:
@@ -134,6 +135,10 @@ class Registration:
                     t = getattr(p, name)
                     if t is not None:
                         t.record_stream(cur)         # allocated on the producer's stream, consumed here
+                        t.record_stream(fin_stream)
+            else:
+                for name in ("src_centered", "tgt_mean"):
+                    getattr(p, name).record_stream(fin_stream)
             preps[i] = p
             return i, p
 
@@ -144,6 +149,8 @@ class Registration:
             eng.park(slot)
         # Pipelined control loop: the states of chunk k are read back while chunk k+1 runs, so the GPU
         # never waits for the host; a slot that finishes in chunk k is refilled before chunk k+2.
+        fin_done = {}                                            # slot -> event: its parameters have been consumed
+        main = torch.cuda.current_stream(dev)
         active, free, exhausted = {}, list(range(B)), False      # active: slot -> (pair index, first valid snapshot)
         nxt = first
         m = self.config.m
@@ -159,6 +166,8 @@ class Registration:
                 i, p = nxt
                 nxt = None
                 slot = free.pop()
+                if slot in fin_done:
+                    main.wait_event(fin_done.pop(slot))          # the previous tenant's final warp read these params
                 eng.load(slot, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.store)
                 active[slot] = (i, seq)                          # snapshots >= seq see this pair in the slot
             if not active and pending is None:
@@ -178,11 +187,19 @@ class Registration:
                         continue
                     del active[slot]
                     p = preps[i]
-                    p.result = self._finish(eng, slot, p, st)
+                    # the snapshot proves every tick that touched this slot has completed: the final warp
+                    # needs no dependency on the main stream, only the slot's refill must wait for it
+                    with torch.cuda.stream(fin_stream):
+                        p.result = self._finish(eng, slot, p, st)
+                        ev = torch.cuda.Event()
+                        ev.record(fin_stream)
+                    fin_done[slot] = ev
+                    p.result.record_stream(main)
                     p.state = st
                     eng.park(slot)
                     free.append(slot)
             pending = handle
+        main.wait_stream(fin_stream)
         self.last_states = [p.state for p in preps]
         return [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
 
