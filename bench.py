@@ -5,8 +5,8 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One *step* registers `--pairs-per-step` (default 256 = 4 x `--slots`) synthetic 8192-point pairs per GPU,
-`--slots` (default 64) of them resident on the device at any time, with the shipped
+One *step* registers `--pairs-per-step` (default 512 = 4 x `--slots`) synthetic 8192-point pairs per GPU,
+`--slots` (default 128) of them resident on the device at any time, with the shipped
 NDP.yaml settings (SE3 / axis-angle, m = 9 levels, 2000 samples per cloud, lr 0.01, early stop on):
 per pair the full Registration.register() work -- pyramid init, centring, sampling, the level/Adam
 loop on the device, and the final warp of all 8192 source points.  The point clouds are resident in
@@ -59,6 +59,18 @@ def kernel_profile(model, pairs, slots, n_ticks=24):
     return {k: v / n_ticks for k, v in zip(names, ms)}, eng, preps, active
 
 
+def pmc_traffic(kernel, pairs):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled
+    per the gfx950 correction, WRITE_SIZE as is; collected by tools/pmc_traffic.sh at 64 pairs per launch and
+    scaled linearly to this launch's pair count).  None when no such profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+    try:
+        rec = json.load(open(path))[kernel]
+        return rec["hbm_bytes_per_launch"] * pairs / rec["pairs_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg, src, tgt):
     """The oracle (oracle/ndp_oracle.c, a parity-pinned C port of the reference path) timed on this
     box's host cores on ONE full pair with the bench's settings."""
@@ -103,7 +115,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--slots", type=int, default=64, help="pairs resident per GPU (= pairs per step per GPU)")
+    ap.add_argument("--slots", type=int, default=128, help="pairs resident per GPU (= pairs per step per GPU)")
     ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 4 x slots)")
     ap.add_argument("--chunk", type=int, default=8, help="ticks between host polls")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -207,7 +219,7 @@ def main():
         ach = flops[dom] * active / (prof[dom] * 1e-3) / 1e12
         tick_ms = sum(prof.values())
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / FP32_PEAK_TFLOPS, "traffic": None,
+                           "frac": ach / FP32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, active),
                            "avg_launch_ms": prof[dom], "pairs_per_launch": active,
                            "algorithmic_flop_per_pair_launch": flops[dom]}
         out["kernels_ms_per_tick"] = prof

@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Drop-in counterpart of the reference's eval_nolearned.py (/root/reference/eval_nolearned.py:26-159)
+for the NDP model on the MI355X path.
+
+    python eval_nolearned.py --config config/NDP.yaml [--batched] [--synthetic N]
+
+Same flow as upstream: seed once, load the YAML (with `!join`), build `Registration(config)`, loop over
+the benchmark pairs, compute the ground-truth scene flow and the overlap mask, `load_pcds` + `register`,
+then `compute_flow_metrics` averaged by `AverageMeter`, then the timer report.  Differences:
+
+* data: the 4DMatch `*.npz` split (keys s_pc, t_pc, s2t_flow, rot, trans, correspondences --
+  correspondence/datasets/_4dmatch.py:60-73) is read when `config.data_root` exists; otherwise
+  (the 14 GB download is not available offline) `--synthetic N` seeded pairs stand in;
+* `--batched` registers all pairs through `Registration.register_batch` (many pairs resident on the
+  GPU); without it the loop calls `register()` pair by pair exactly like upstream;
+* only `deformation_model: NDP` is served (the other models are comparison baselines).
+"""
+import argparse
+import glob
+import os
+
+import numpy as np
+import torch
+
+from deformationpyramid_amd.config import load_config
+from deformationpyramid_amd.loss import compute_flow_metrics
+from deformationpyramid_amd.registration import Registration
+from deformationpyramid_amd.synthetic import synthetic_pair
+from deformationpyramid_amd.utils import AverageMeter, Logger, Timers, setup_seed
+
+
+class FourDMatchPairs:
+    """Minimal reader of the 4DMatch test split: yields (src, tgt, flow_gt, overlap) numpy/torch items
+    with the ground truth built as in eval_nolearned.py:75-84."""
+
+    def __init__(self, root, split, max_points=30000):
+        self.files = glob.glob(os.path.join(root, split, "*/*.npz"))      # raw glob order, as upstream
+        self.max_points = max_points
+
+    def __len__(self):
+        return len(self.files)
+
+    def __getitem__(self, i):
+        e = np.load(self.files[i])
+        src, tgt = e["s_pc"].astype(np.float32), e["t_pc"].astype(np.float32)
+        rot, trn, flow = e["rot"].astype(np.float32), e["trans"].astype(np.float32), e["s2t_flow"].astype(np.float32)
+        corr = e["correspondences"]
+        if src.shape[0] > self.max_points:                                 # _4dmatch.py:93-98
+            idx = np.random.permutation(src.shape[0])[: self.max_points]
+            remap = -np.ones(src.shape[0], dtype=np.int64)
+            remap[idx] = np.arange(idx.size)
+            src, flow = src[idx], flow[idx]
+            corr = corr[remap[corr[:, 0]] >= 0]
+            corr = np.stack([remap[corr[:, 0]], corr[:, 1]], 1)
+        if tgt.shape[0] > self.max_points:
+            tgt = tgt[np.random.permutation(tgt.shape[0])[: self.max_points]]
+        warped = (rot @ (src + flow).T + trn.reshape(3, 1)).T
+        flow_gt = torch.from_numpy((warped - src).astype(np.float32))
+        overlap = np.zeros(src.shape[0], dtype=bool)
+        overlap[corr[:, 0]] = True
+        return torch.from_numpy(src), torch.from_numpy(tgt), flow_gt, torch.from_numpy(overlap)
+
+
+class SyntheticPairs:
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return synthetic_pair(i)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, default="config/NDP.yaml", help="Path to the config file.")
+    ap.add_argument("--visualize", action="store_true", help="(upstream flag; mayavi is out of scope here)")
+    ap.add_argument("--batched", action="store_true", help="register all pairs through register_batch")
+    ap.add_argument("--slots", type=int, default=64)
+    ap.add_argument("--synthetic", type=int, default=32, help="pairs to generate when the dataset is absent")
+    args = ap.parse_args()
+    setup_seed(0)                                                           # once per process, as upstream
+    config = load_config(args.config, make_dirs=True)
+    if config.deformation_model != "NDP":
+        raise KeyError(config.deformation_model)
+    model = Registration(config)
+    timer = Timers()
+    for benchmark in ["4DMatch-F", "4DLoMatch-F"]:
+        config.split["test"] = benchmark
+        root = os.path.join(config.data_root, benchmark)
+        if os.path.isdir(root):
+            data = FourDMatchPairs(config.data_root, benchmark)
+        else:
+            print(f"[{benchmark}] {root} not found: using {args.synthetic} synthetic pairs")
+            data = SyntheticPairs(args.synthetic)
+        logger = Logger(os.path.join(config.snapshot_dir, benchmark + ".log"))
+        items = [data[i] for i in range(len(data))]
+        if args.batched:
+            timer.tic("registration")
+            results = model.register_batch([(s, t) for s, t, _, _ in items], slots=args.slots)
+            torch.cuda.synchronize()
+            timer.toc("registration")
+            flows = [w.cpu() - s for (w, _), (s, _, _, _) in zip(results, items)]
+        else:
+            flows = []
+            for src, tgt, _, _ in items:
+                model.load_pcds(src, tgt)
+                timer.tic("registration")
+                warped, iter_cnt, timer = model.register(visualize=args.visualize, timer=timer)
+                timer.toc("registration")
+                flows.append((warped - model.src_pcd).cpu())
+        meters = None
+        for flow, (_, _, flow_gt, overlap) in zip(flows, items):
+            info = compute_flow_metrics(flow, flow_gt, overlap=overlap)
+            if meters is None:
+                meters = {k: AverageMeter() for k in info}
+            for k, v in info.items():
+                meters[k].update(v)
+        message = f"{len(items)}/{len(items)}: " + "".join(f"{k}: {m.avg:.3f}\t" for k, m in meters.items())
+        logger.write(message + "\n")
+        print("score on ", benchmark, "\n", message)
+        if not os.path.isdir(root):
+            break                                                           # one synthetic benchmark is enough
+    print("time cost average")
+    for line in timer.get_strings():
+        print(line)
+
+
+if __name__ == "__main__":
+    main()
