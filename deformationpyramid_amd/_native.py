@@ -112,7 +112,8 @@ def lib(allow_build=True):
             build()
         if not os.path.exists(LIBPATH):
             raise NdpError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-        L = ctypes.CDLL(LIBPATH)
+        # NDP_HIP_LIB: developer override for timing-only experiment builds
+        L = ctypes.CDLL(os.environ.get("NDP_HIP_LIB", LIBPATH))
         L.ndp_version.restype = I
         L.ndp_last_error.restype = ctypes.c_char_p
         for name, args in _SIGS.items():

@@ -165,8 +165,10 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
             const int p = base + lane;
             const float xa = p < job.n ? job.x_in[3 * p + wv] : 0.f;
             const float phs = xa * job.freq;
-            pe[lane * 9 + 2 * wv] = sinf(phs);
-            pe[lane * 9 + 2 * wv + 1] = cosf(phs);
+            float sn, cs;
+            sincosf(phs, &sn, &cs);
+            pe[lane * 9 + 2 * wv] = sn;
+            pe[lane * 9 + 2 * wv + 1] = cs;
             xs[4 * lane + wv] = xa;
         }
         __syncthreads();
@@ -228,17 +230,18 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
             const float *hrow = bufA + lane * NDP_LD;
             for (int j = wv; j < hc.nh; j += 4) {
                 const float *wr = whs + j * NDP_W;
-                float acc = bhs[j];
+                // four independent fmaf chains (k mod 4): a lone 128-long chain is pure FMA latency
+                float a0 = bhs[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll 8
                 for (int k4 = 0; k4 < 32; ++k4) {
                     const float4 hv = *reinterpret_cast<const float4 *>(hrow + 4 * k4);
                     const float4 wv4 = *reinterpret_cast<const float4 *>(wr + 4 * k4);
-                    acc = fmaf(wv4.x, hv.x, acc);
-                    acc = fmaf(wv4.y, hv.y, acc);
-                    acc = fmaf(wv4.z, hv.z, acc);
-                    acc = fmaf(wv4.w, hv.w, acc);
+                    a0 = fmaf(wv4.x, hv.x, a0);
+                    a1 = fmaf(wv4.y, hv.y, a1);
+                    a2 = fmaf(wv4.z, hv.z, a2);
+                    a3 = fmaf(wv4.w, hv.w, a3);
                 }
-                ho[lane * NDP_NHMAX + j] = hc.mlp_scale * acc;
+                ho[lane * NDP_NHMAX + j] = hc.mlp_scale * ((a0 + a1) + (a2 + a3));
             }
         }
         __syncthreads();
