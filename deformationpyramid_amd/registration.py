@@ -190,9 +190,10 @@ class Registration:
                     # the snapshot proves every tick that touched this slot has completed: the final warp
                     # needs no dependency on the main stream, only the slot's refill must wait for it
                     with torch.cuda.stream(fin_stream):
-                        p.result = self._finish(eng, slot, p, st)
+                        frozen = eng.params[slot].clone()            # 1.25 MB device copy: the slot is free again
                         ev = torch.cuda.Event()
                         ev.record(fin_stream)
+                        p.result = self._finish(eng, slot, p, st, store=frozen)
                     fin_done[slot] = ev
                     p.result.record_stream(main)
                     p.state = st
@@ -276,9 +277,10 @@ class Registration:
             self._engines[key] = BatchedEngine(desc, cfg, B, n_cap, t_cap, self._dev())
         return self._engines[key]
 
-    def _finish(self, eng, slot, prep, st):
+    def _finish(self, eng, slot, prep, st, store=None):
         """registration.py:253-262: warp ALL source points through the optimised pyramid, add tgt_mean."""
         c = self.config
-        store = eng.params[slot]                                                  # [m, p_stride] on device
+        if store is None:
+            store = eng.params[slot]                                              # [m, p_stride] on device
         warped = ops.pyramid_fwd(prep.desc, c.m, c.k0, store, prep.src_centered)
         return warped + prep.tgt_mean
