@@ -76,10 +76,12 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise NdpError("hipcc not found and libndp_hip.so is missing or stale")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIBPATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    tmp = f"{LIBPATH}.{os.getpid()}.tmp"              # build aside + atomic rename: concurrent ranks never see a torn file
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, LIBPATH)
     return LIBPATH
 
 
@@ -108,7 +110,10 @@ def lib(allow_build=True):
     """Load the native library (building it first if the source is newer and hipcc exists)."""
     global _LIB
     if _LIB is None:
-        if allow_build and _stale() and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        # Build only when the library is absent (or NDP_REBUILD=1 asks for a staleness check): file times do not
+        # survive every copy of the tree, and N ranks must never race to rebuild the same .so.
+        want = (not os.path.exists(LIBPATH)) or (os.environ.get("NDP_REBUILD") == "1" and _stale())
+        if allow_build and want and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
             build()
         if not os.path.exists(LIBPATH):
             raise NdpError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
@@ -137,16 +142,17 @@ class DrawOp(ctypes.Structure):
 def build_host(force=False):
     if force or not os.path.exists(HOST_LIBPATH) or os.path.getmtime(HOST_LIBPATH) < os.path.getmtime(HOST_SOURCE):
         os.makedirs(LIBDIR, exist_ok=True)
+        tmp = f"{HOST_LIBPATH}.{os.getpid()}.tmp"
         subprocess.check_call(["g++", "-O3", "-std=c++17", "-ffp-contract=off", "-mfma", "-fPIC", "-shared",
-                               "-o", HOST_LIBPATH, HOST_SOURCE])
+                               "-o", tmp, HOST_SOURCE])
+        os.replace(tmp, HOST_LIBPATH)
     return HOST_LIBPATH
 
 
 def host_lib():
     global _HOST
     if _HOST is None:
-        if not os.path.exists(HOST_LIBPATH) or (os.path.exists(HOST_SOURCE) and shutil.which("g++")
-                                                and os.path.getmtime(HOST_LIBPATH) < os.path.getmtime(HOST_SOURCE)):
+        if not os.path.exists(HOST_LIBPATH):
             build_host()
         L = ctypes.CDLL(HOST_LIBPATH)
         L.ndp_rng_replay.argtypes = [V, ctypes.c_longlong, ctypes.POINTER(DrawOp), I, I, V, ctypes.c_longlong]

@@ -40,8 +40,12 @@ def make_desc(width=128, n_hidden=2, motion="SE3", rotfmt="axis_angle", nonrigid
 def build(force=False):
     so = os.path.join(_HERE, "libndp_oracle.so")
     src = os.path.join(_HERE, "ndp_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    stale = os.environ.get("NDP_REBUILD") == "1" and os.path.exists(so) and os.path.getmtime(so) < os.path.getmtime(src)
+    if force or not os.path.exists(so) or stale:
+        tmp = f"{so}.{os.getpid()}.tmp"               # same flags as oracle/Makefile; atomic rename for concurrent ranks
+        subprocess.check_call(["gcc", "-O2", "-fopenmp", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-std=c11",
+                               "-shared", "-o", tmp, src, "-lm"])
+        os.replace(tmp, so)
     return so
 
 
