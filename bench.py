@@ -125,11 +125,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # NDP_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with ONE GPU (all ranks share cuda:0, the
+    # aggregate goes over gloo on the CPU); the real multi-GPU run uses RCCL ("nccl") with one GPU per rank.
+    backend = os.environ.get("NDP_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = max(world, 1)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -180,7 +188,7 @@ def main():
 
     vals = torch.tensor([float(args.steps * NP), float(steps_total), float(evals_total)] + list(msum) + [float(NP)],
                         dtype=torch.float64)
-    agg, elapsed = aggregate(vals, elapsed, dev)             # the single collective: SUM + MAX over RCCL
+    agg, elapsed = aggregate(vals, elapsed, torch.device("cpu") if backend == "gloo" else dev)   # the single collective: SUM + MAX (RCCL)
     agg = agg.numpy()
     n_pairs, n_steps, n_evals = agg[0], agg[1], agg[2]
     metrics = {k: float(v / agg[-1]) for k, v in zip(keys, agg[3:-1])}

@@ -93,35 +93,45 @@ class BatchedEngine:
         self.c_engine = e
 
     # ------------------------------------------------------------------ slot management
+    # Nothing here may block the host: every copy is device->device or pinned->device (a pageable H2D copy is
+    # synchronous and would drain the tick pipeline behind it -- it used to cost 0.25-0.45 ms per call).
+    def _templates(self):
+        if not hasattr(self, "_st_fresh"):
+            st = N.PairState()
+            st.loss_prev = 1e6
+            self._st_fresh = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
+            st = N.PairState()
+            st.level = self.cfg.m
+            self._st_parked = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
+            self._geom_pin = torch.zeros(self.B, 4, dtype=torch.int32).pin_memory()
+        return self._st_fresh, self._st_parked
+
     def load(self, slot, pts, K, S, ldmk_t, tgt, params):
         """pts [K+S,3] centred source points (landmarks first); ldmk_t [K,3]; tgt [T,3];
-        params [m, >=P] initial parameters of every level.  All tensors may live on any device."""
+        params [m, >=P] initial parameters of every level (device tensor, or pinned/pageable host tensor)."""
         n = K + S
         T = 0 if tgt is None else tgt.shape[0]
         if n > self.n_cap or T > self.t_cap or n < 1:
             raise ValueError(f"pair does not fit the engine capacities: n={n}/{self.n_cap}, T={T}/{self.t_cap}")
+        fresh, _ = self._templates()
         self.pts[slot].zero_()
-        self.pts[slot, 0, :n] = pts.to(self.device, torch.float32)
+        self.pts[slot, 0, :n].copy_(pts, non_blocking=True)
         if K:
-            self.ldmk_t[slot, :K] = ldmk_t.to(self.device, torch.float32)
+            self.ldmk_t[slot, :K].copy_(ldmk_t, non_blocking=True)
         if T:
-            self.tgt[slot, :T] = tgt.to(self.device, torch.float32)
-        self.params[slot, :, :self.P] = params[:, :self.P].to(self.device, torch.float32)
+            self.tgt[slot, :T].copy_(tgt, non_blocking=True)
+        self.params[slot, :, :self.P].copy_(params[:, :self.P], non_blocking=True)
         self.adam_m[slot].zero_()
         self.adam_v[slot].zero_()
         self._geom_h[slot] = (K, S, T, 0)
-        self.geom[slot] = torch.from_numpy(self._geom_h[slot]).to(self.device)
-        st = N.PairState()
-        st.loss_prev = 1e6
-        buf = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
-        self.state[self.tick & 1, slot] = buf
+        self._geom_pin[slot] = torch.tensor([K, S, T, 0], dtype=torch.int32)
+        self.geom[slot].copy_(self._geom_pin[slot], non_blocking=True)
+        self.state[self.tick & 1, slot].copy_(fresh, non_blocking=True)
 
     def park(self, slot):
         """Mark a slot as finished (empty)."""
-        st = N.PairState()
-        st.level = self.cfg.m
-        buf = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
-        self.state[self.tick & 1, slot] = buf
+        _, parked = self._templates()
+        self.state[self.tick & 1, slot].copy_(parked, non_blocking=True)
 
     def run_ticks(self, n_ticks):
         N.check(self.lib.ndp_engine_run(ctypes.byref(self.c_engine), self.tick, int(n_ticks),

@@ -107,13 +107,14 @@ def _native_rng_ok():
 _OPS_CACHE = {}
 
 
-def init_pyramid_store(descs, depth, p_stride, native=True):
+def init_pyramid_store(descs, depth, p_stride, native=True, out=None):
     """[m, p_stride] CPU tensor with every level initialised in order (the RNG replay of
     Deformation_Pyramid.__init__, nets.py:20-30) -- the part of the constructor the batched
     registration path needs, without the per-name Parameter views.  With native=True the draws
     are produced by libndp_host.so (bit-identical to torch's generator, ~4x faster)."""
     descs = list(descs)
-    store = torch.empty(len(descs), p_stride, dtype=torch.float32)
+    store = out if out is not None else torch.empty(len(descs), p_stride, dtype=torch.float32)
+    assert store.shape == (len(descs), p_stride) and store.dtype == torch.float32 and store.is_contiguous()
     if native and _native_rng_ok():
         from . import _native as N
         key = (tuple(descs), depth, p_stride)

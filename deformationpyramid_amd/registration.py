@@ -131,7 +131,7 @@ class Registration:
             if ev is not None:
                 cur = torch.cuda.current_stream(dev)
                 cur.wait_event(ev)
-                for name in ("src_centered", "tgt_mean", "pts", "ldmk_t", "tgt_sample", "src_pcd"):
+                for name in ("src_centered", "tgt_mean", "pts", "ldmk_t", "tgt_sample", "src_pcd", "store"):
                     t = getattr(p, name)
                     if t is not None:
                         t.record_stream(cur)         # allocated on the producer's stream, consumed here
@@ -234,7 +234,12 @@ class Registration:
         p = _Prepared()
         # registration.py:133-140 -- all m levels are initialised up front on the CPU generator
         p.desc = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format)
-        p.store = init_pyramid_store([p.desc] * c.m, c.depth, (p.desc.param_count + 63) // 64 * 64)
+        stride = (p.desc.param_count + 63) // 64 * 64
+        host = self._pinned_store(c.m, stride)                                     # reused pinned staging buffer
+        init_pyramid_store([p.desc] * c.m, c.depth, stride, out=host)
+        p.store = host.to(dev, non_blocking=True)                                  # async upload on the current stream
+        self._pin_busy.append((host, torch.cuda.Event()))
+        self._pin_busy[-1][1].record(torch.cuda.current_stream(dev))
         src_pcd = src_pcd.to(dev).float()
         tgt_pcd = tgt_pcd.to(dev).float()
         p.src_pcd = src_pcd
@@ -264,6 +269,23 @@ class Registration:
             p.tgt_sample = t_sample.contiguous()
         p.result = p.state = None
         return p
+
+    def _pinned_store(self, m, stride):
+        """A pinned [m, stride] host buffer whose previous upload has completed (small ring, allocated once:
+        cudaHostAlloc costs milliseconds)."""
+        if not hasattr(self, "_pin_free"):
+            self._pin_free, self._pin_busy = [], []
+        while self._pin_busy and self._pin_busy[0][1].query():
+            self._pin_free.append(self._pin_busy.pop(0)[0])
+        for i, buf in enumerate(self._pin_free):
+            if buf.shape == (m, stride):
+                return self._pin_free.pop(i)
+        if len(self._pin_busy) >= 64:                                               # bound the ring: wait for the oldest
+            host, ev = self._pin_busy.pop(0)
+            ev.synchronize()
+            if host.shape == (m, stride):
+                return host
+        return torch.empty(m, stride, dtype=torch.float32).pin_memory()
 
     def _engine(self, B, like, n_hint=0):
         n_cap = ops.cap(max(like.K + like.S, n_hint))
