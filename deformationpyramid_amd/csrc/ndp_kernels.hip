@@ -1286,7 +1286,7 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
 }
 
 // Profiling variant of ndp_engine_run: HIP events around every kernel of every tick, recorded on the
-// launch stream; ms_out[6] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwdh + k_eng_bwd2, k_eng_bwd1, k_eng_update.
+// launch stream; ms_out[7] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwdh, k_eng_bwd2, k_eng_bwd1, k_eng_update.
 // Synchronises the stream before returning.  Used by bench.py for the roofline figures only.
 extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out) {
     if (!e || !ms_out || n_ticks < 1 || n_ticks > 4096) return fail(NDP_E_INVALID, "ndp_engine_run_timed: bad arguments");
@@ -1302,7 +1302,7 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const bool nn = e->w_cd != 0.f && e->d2x;
     const dim3 g_loss((e->n_cap + 255) / 256, e->B);
-    const int per = 7;
+    const int per = 8;
     hipEvent_t *ev = new hipEvent_t[(size_t)n_ticks * per];
     for (int i = 0; i < n_ticks * per; ++i) (void)hipEventCreate(&ev[i]);
     for (int k = 0; k < n_ticks; ++k) {
@@ -1316,18 +1316,19 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
         hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         (void)hipEventRecord(q[3], s);
         hipLaunchKernelGGL(k_eng_bwdh, g_lvl, blk, kSmemBwdHBytes, s, *e, parity);
-        hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         (void)hipEventRecord(q[4], s);
-        hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         (void)hipEventRecord(q[5], s);
-        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         (void)hipEventRecord(q[6], s);
+        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        (void)hipEventRecord(q[7], s);
     }
     hipError_t err = hipStreamSynchronize(s);
-    for (int j = 0; j < 6; ++j) ms_out[j] = 0.f;
+    for (int j = 0; j < 7; ++j) ms_out[j] = 0.f;
     if (err == hipSuccess) {
         for (int k = 0; k < n_ticks; ++k)
-            for (int j = 0; j < 6; ++j) {
+            for (int j = 0; j < 7; ++j) {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, ev[(size_t)k * per + j], ev[(size_t)k * per + j + 1]);
                 ms_out[j] += ms;

@@ -144,8 +144,9 @@ typedef struct ndp_engine {
  * Asynchronous on `stream`; read state[(tick0 + n_ticks) & 1] after synchronising.              */
 int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream);
 
-/* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[6] (HOST memory)
- * receives the summed durations of the forward, NN, loss/gradient, backward-2, backward-1 and update kernels over the
+/* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[7] (HOST memory)
+ * receives the summed durations of the forward, NN, loss/gradient, backward-heads, backward-2, backward-1 and
+ * update kernels over the
  * n_ticks ticks.  Synchronises `stream`.  Measurement aid for bench.py (roofline), not a product path. */
 int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out);
 
