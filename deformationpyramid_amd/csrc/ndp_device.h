@@ -74,6 +74,8 @@ struct PointHead {
     float R[9];
     float theta, w[3], sn, cs, K[9];                 // axis-angle
     float Mx[9], My[9], Mz[9], A[9], se[3], ce[3];   // euler
+    float q[4], qd, ts;                              // quaternion
+    float b1[3], b2[3], n1, nu, cdot;                // 6D
     float rx[3], s;
 };
 
@@ -101,7 +103,7 @@ __device__ __forceinline__ void rot_fwd(int rotfmt, const float *r, PointHead &c
             const float I = (i == 0 || i == 4 || i == 8) ? 1.0f : 0.0f;
             c.R[i] = (I + c.sn * c.K[i]) + P[i];
         }
-    } else {
+    } else if (rotfmt == NDP_ROT_EULER) {
         // rigid_body.py:19-56, convention X,Y,Z: R = (Mx My) Mz
 #pragma unroll
         for (int i = 0; i < 3; ++i) { c.se[i] = sinf(r[i]); c.ce[i] = cosf(r[i]); }
@@ -111,10 +113,54 @@ __device__ __forceinline__ void rot_fwd(int rotfmt, const float *r, PointHead &c
         c.Mz[0] = k[2]; c.Mz[1] = -s[2]; c.Mz[2] = 0; c.Mz[3] = s[2]; c.Mz[4] = k[2]; c.Mz[5] = 0; c.Mz[6] = 0; c.Mz[7] = 0; c.Mz[8] = 1;
         mat3_mul(c.Mx, c.My, c.A);
         mat3_mul(c.A, c.Mz, c.R);
+    } else if (rotfmt == NDP_ROT_QUATERNION) {
+        // nets.py:155-157 + rigid_body.py:58-85
+        float s2 = r[0] * r[0];
+        s2 = fmaf(r[1], r[1], s2); s2 = fmaf(r[2], r[2], s2); s2 = fmaf(r[3], r[3], s2);
+        const float nrm = sqrtf(s2);
+        c.qd = (r[0] < 0.f) ? -nrm : nrm;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) c.q[i] = r[i] / c.qd;
+        const float qr = c.q[0], qi = c.q[1], qj = c.q[2], qk = c.q[3];
+        float n2 = qr * qr;
+        n2 = fmaf(qi, qi, n2); n2 = fmaf(qj, qj, n2); n2 = fmaf(qk, qk, n2);
+        c.ts = 2.0f / n2;
+        const float ts = c.ts;
+        c.R[0] = 1.0f - ts * (qj * qj + qk * qk); c.R[1] = ts * (qi * qj - qk * qr); c.R[2] = ts * (qi * qk + qj * qr);
+        c.R[3] = ts * (qi * qj + qk * qr); c.R[4] = 1.0f - ts * (qi * qi + qk * qk); c.R[5] = ts * (qj * qk - qi * qr);
+        c.R[6] = ts * (qi * qk - qj * qr); c.R[7] = ts * (qj * qk + qi * qr); c.R[8] = 1.0f - ts * (qi * qi + qj * qj);
+    } else {
+        // rigid_body.py:5-16 (6D): Gram-Schmidt on (a1, a2), rows (b1, b2, b1 x b2)
+        const float *a1 = r, *a2 = r + 3;
+        float n1 = a1[0] * a1[0];
+        n1 = fmaf(a1[1], a1[1], n1); n1 = fmaf(a1[2], a1[2], n1);
+        n1 = sqrtf(n1);
+        c.n1 = n1 > 1e-12f ? n1 : 1e-12f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c.b1[i] = a1[i] / c.n1;
+        float cd = c.b1[0] * a2[0];
+        cd = fmaf(c.b1[1], a2[1], cd); cd = fmaf(c.b1[2], a2[2], cd);
+        c.cdot = cd;
+        float u[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) u[i] = a2[i] - cd * c.b1[i];
+        float nu = u[0] * u[0];
+        nu = fmaf(u[1], u[1], nu); nu = fmaf(u[2], u[2], nu);
+        nu = sqrtf(nu);
+        c.nu = nu > 1e-12f ? nu : 1e-12f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) c.b2[i] = u[i] / c.nu;
+        const float *b1 = c.b1, *b2 = c.b2;
+        c.R[0] = b1[0]; c.R[1] = b1[1]; c.R[2] = b1[2];
+        c.R[3] = b2[0]; c.R[4] = b2[1]; c.R[5] = b2[2];
+        c.R[6] = b1[1] * b2[2] - b1[2] * b2[1];
+        c.R[7] = b1[2] * b2[0] - b1[0] * b2[2];
+        c.R[8] = b1[0] * b2[1] - b1[1] * b2[0];
     }
 }
 
-__device__ __forceinline__ void rot_bwd(int rotfmt, const PointHead &c, const float *G, float *dr) {
+__device__ __forceinline__ void rot_bwd(int rotfmt, const float *r, const PointHead &c, const float *G, float *dr) {
+    const float *a2in = r + 3;       // 6D only: the raw second vector
     if (rotfmt == NDP_ROT_AXIS_ANGLE) {
         const float *K = c.K;
         const float c1 = 1.0f - c.cs;
@@ -139,7 +185,7 @@ __device__ __forceinline__ void rot_bwd(int rotfmt, const PointHead &c, const fl
         dth -= wdotdw / th;
 #pragma unroll
         for (int i = 0; i < 3; ++i) dr[i] = fmaf(dth, c.w[i], dw[i] / th);
-    } else {
+    } else if (rotfmt == NDP_ROT_EULER) {
         float dA[9], dMz[9], dMx[9], dMy[9];
         mat3_mul_nt(G, c.Mz, dA);
         mat3_mul_tn(c.A, G, dMz);
@@ -149,6 +195,55 @@ __device__ __forceinline__ void rot_bwd(int rotfmt, const PointHead &c, const fl
         dr[0] = (dMx[7] - dMx[5]) * k[0] - (dMx[4] + dMx[8]) * s[0];
         dr[1] = (dMy[2] - dMy[6]) * k[1] - (dMy[0] + dMy[8]) * s[1];
         dr[2] = (dMz[3] - dMz[1]) * k[2] - (dMz[0] + dMz[4]) * s[2];
+    } else if (rotfmt == NDP_ROT_QUATERNION) {
+        const float qr = c.q[0], qi = c.q[1], qj = c.q[2], qk = c.q[3], ts = c.ts;
+        const float M[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr,
+                            qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr,
+                            qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)};
+        float dts = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) dts = fmaf(G[i], M[i], dts);
+        float dq[4];
+        dq[0] = ts * (-qk * G[1] + qj * G[2] + qk * G[3] - qi * G[5] - qj * G[6] + qi * G[7]);
+        dq[1] = ts * (qj * G[1] + qk * G[2] + qj * G[3] - 2.f * qi * G[4] - qr * G[5] + qk * G[6] + qr * G[7] - 2.f * qi * G[8]);
+        dq[2] = ts * (-2.f * qj * G[0] + qi * G[1] + qr * G[2] + qi * G[3] + qk * G[5] - qr * G[6] + qk * G[7] - 2.f * qj * G[8]);
+        dq[3] = ts * (-2.f * qk * G[0] - qr * G[1] + qi * G[2] + qr * G[3] - 2.f * qk * G[4] + qj * G[5] + qi * G[6] + qj * G[7]);
+        float n2 = qr * qr;
+        n2 = fmaf(qi, qi, n2); n2 = fmaf(qj, qj, n2); n2 = fmaf(qk, qk, n2);
+        const float dn2 = dts * (-2.0f / (n2 * n2));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dq[i] = fmaf(dn2, 2.0f * c.q[i], dq[i]);
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dot = fmaf(dq[i], c.q[i], dot);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dr[i] = (dq[i] - dot * c.q[i]) / c.qd;
+    } else {
+        const float *b1 = c.b1, *b2 = c.b2;
+        const float *g1 = G, *g2 = G + 3, *g3 = G + 6;
+        float db1[3] = {g1[0] + (b2[1] * g3[2] - b2[2] * g3[1]), g1[1] + (b2[2] * g3[0] - b2[0] * g3[2]),
+                        g1[2] + (b2[0] * g3[1] - b2[1] * g3[0])};
+        float db2[3] = {g2[0] + (g3[1] * b1[2] - g3[2] * b1[1]), g2[1] + (g3[2] * b1[0] - g3[0] * b1[2]),
+                        g2[2] + (g3[0] * b1[1] - g3[1] * b1[0])};
+        float d2b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d2b = fmaf(db2[i], b2[i], d2b);
+        float du[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) du[i] = (db2[i] - d2b * b2[i]) / c.nu;
+        float dub1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dub1 = fmaf(du[i], b1[i], dub1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            dr[3 + i] = du[i] - dub1 * b1[i];
+            db1[i] = db1[i] - c.cdot * du[i] - dub1 * a2in[i];
+        }
+        float d1b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) d1b = fmaf(db1[i], b1[i], d1b);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dr[i] = (db1[i] - d1b * b1[i]) / c.n1;
     }
 }
 
@@ -183,6 +278,10 @@ __device__ __forceinline__ void head_warp_fwd(const HeadCfg &hc, const float *o,
 // addressed with run-time offsets, which registers cannot do); unused rows are zeroed.
 __device__ __forceinline__ void head_warp_bwd(const HeadCfg &hc, const float *x, const PointHead &c,
                                               const float *g, float *d_o) {
+    // the 6D backward needs the raw rot outputs: read them before the row is reused for the gradient
+    float rraw[6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) rraw[a] = d_o[a];
 #pragma unroll
     for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(d_o + j) = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
@@ -202,10 +301,11 @@ __device__ __forceinline__ void head_warp_bwd(const HeadCfg &hc, const float *x,
     for (int a = 0; a < 3; ++a)
 #pragma unroll
         for (int b = 0; b < 3; ++b) G[a * 3 + b] = grx[a] * x[b];
-    float dr[3];
-    rot_bwd(hc.rotfmt, c, G, dr);
+    float dr[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    rot_bwd(hc.rotfmt, rraw, c, G, dr);
 #pragma unroll
-    for (int a = 0; a < 3; ++a) d_o[a] = dr[a];
+    for (int a = 0; a < 6; ++a)
+        if (a < hc.n_rot) d_o[a] = dr[a];
 }
 
 // deterministic block-wide sum (256 threads); every thread gets the result

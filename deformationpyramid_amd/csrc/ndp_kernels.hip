@@ -1122,8 +1122,8 @@ static int check_desc(const ndp_layer_desc *d) {
         return fail(NDP_E_UNSUPPORTED, "kernels are specialised for width=128, depth=3");
     if (d->nonrigidity) return fail(NDP_E_UNSUPPORTED, "nonrigidity gate (w_reg > 0) not implemented in the HIP path yet");
     if (d->motion < 0 || d->motion > 2) return fail(NDP_E_INVALID, "bad motion type");
-    if (d->motion != NDP_MOTION_SFLOW && d->rotfmt != NDP_ROT_AXIS_ANGLE && d->rotfmt != NDP_ROT_EULER)
-        return fail(NDP_E_UNSUPPORTED, "rotation_format must be axis_angle or euler in the HIP path");
+    if (d->motion != NDP_MOTION_SFLOW && (d->rotfmt < NDP_ROT_AXIS_ANGLE || d->rotfmt > NDP_ROT_6D))
+        return fail(NDP_E_INVALID, "bad rotation_format");
     return 0;
 }
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }

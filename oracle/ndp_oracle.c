@@ -70,6 +70,10 @@ typedef struct rot_ctx {
     float theta, w[3], sn, cs, K[9];
     /* euler intermediates (rigid_body.py:19-56) */
     float Mx[9], My[9], Mz[9], A[9], se[3], ce[3];
+    /* quaternion intermediates (nets.py:154-157, rigid_body.py:58-85) */
+    float q[4], qd, ts;
+    /* 6D intermediates (rigid_body.py:5-16) */
+    float b1[3], b2[3], n1, nu, cdot;
 } rot_ctx;
 
 static void rot_fwd(int rotfmt, const float *r, rot_ctx *c) {
@@ -91,7 +95,7 @@ static void rot_fwd(int rotfmt, const float *r, rot_ctx *c) {
             float I = (i == 0 || i == 4 || i == 8) ? 1.0f : 0.0f;
             c->R[i] = (I + c->sn * c->K[i]) + P[i];
         }
-    } else { /* NDP_ROT_EULER: R = (Mx My) Mz, convention X,Y,Z (rigid_body.py:19,56) */
+    } else if (rotfmt == NDP_ROT_EULER) { /* R = (Mx My) Mz, convention X,Y,Z (rigid_body.py:19,56) */
         for (int i = 0; i < 3; ++i) { c->se[i] = sinf(r[i]); c->ce[i] = cosf(r[i]); }
         const float *s = c->se, *k = c->ce;
         float Mx[9] = {1, 0, 0, 0, k[0], -s[0], 0, s[0], k[0]};
@@ -100,6 +104,44 @@ static void rot_fwd(int rotfmt, const float *r, rot_ctx *c) {
         memcpy(c->Mx, Mx, sizeof Mx); memcpy(c->My, My, sizeof My); memcpy(c->Mz, Mz, sizeof Mz);
         mat3_mul(c->Mx, c->My, c->A);
         mat3_mul(c->A, c->Mz, c->R);
+    } else if (rotfmt == NDP_ROT_QUATERNION) {
+        /* nets.py:155-157: s = sum(r*r); q = r / copysign(sqrt(s), r0); then quaternion_to_SO3 (rigid_body.py:64-85) */
+        float s2 = r[0] * r[0];
+        s2 = fmaf(r[1], r[1], s2); s2 = fmaf(r[2], r[2], s2); s2 = fmaf(r[3], r[3], s2);
+        const float nrm = sqrtf(s2);
+        c->qd = (r[0] < 0.f) ? -nrm : nrm;                      /* rigid_body.py:58-60 (_copysign) */
+        for (int i = 0; i < 4; ++i) c->q[i] = r[i] / c->qd;
+        const float qr = c->q[0], qi = c->q[1], qj = c->q[2], qk = c->q[3];
+        float n2 = qr * qr;
+        n2 = fmaf(qi, qi, n2); n2 = fmaf(qj, qj, n2); n2 = fmaf(qk, qk, n2);
+        c->ts = 2.0f / n2;
+        const float ts = c->ts;
+        c->R[0] = 1.0f - ts * (qj * qj + qk * qk); c->R[1] = ts * (qi * qj - qk * qr); c->R[2] = ts * (qi * qk + qj * qr);
+        c->R[3] = ts * (qi * qj + qk * qr); c->R[4] = 1.0f - ts * (qi * qi + qk * qk); c->R[5] = ts * (qj * qk - qi * qr);
+        c->R[6] = ts * (qi * qk - qj * qr); c->R[7] = ts * (qj * qk + qi * qr); c->R[8] = 1.0f - ts * (qi * qi + qj * qj);
+    } else { /* NDP_ROT_6D, rigid_body.py:5-16: Gram-Schmidt on (a1, a2), rows (b1, b2, b1 x b2) */
+        const float *a1 = r, *a2 = r + 3;
+        float n1 = a1[0] * a1[0];
+        n1 = fmaf(a1[1], a1[1], n1); n1 = fmaf(a1[2], a1[2], n1);
+        n1 = sqrtf(n1);
+        c->n1 = n1 > 1e-12f ? n1 : 1e-12f;                       /* F.normalize eps */
+        for (int i = 0; i < 3; ++i) c->b1[i] = a1[i] / c->n1;
+        float cd = c->b1[0] * a2[0];
+        cd = fmaf(c->b1[1], a2[1], cd); cd = fmaf(c->b1[2], a2[2], cd);
+        c->cdot = cd;
+        float u[3];
+        for (int i = 0; i < 3; ++i) u[i] = a2[i] - cd * c->b1[i];
+        float nu = u[0] * u[0];
+        nu = fmaf(u[1], u[1], nu); nu = fmaf(u[2], u[2], nu);
+        nu = sqrtf(nu);
+        c->nu = nu > 1e-12f ? nu : 1e-12f;
+        for (int i = 0; i < 3; ++i) c->b2[i] = u[i] / c->nu;
+        const float *b1 = c->b1, *b2 = c->b2;
+        c->R[0] = b1[0]; c->R[1] = b1[1]; c->R[2] = b1[2];
+        c->R[3] = b2[0]; c->R[4] = b2[1]; c->R[5] = b2[2];
+        c->R[6] = b1[1] * b2[2] - b1[2] * b2[1];
+        c->R[7] = b1[2] * b2[0] - b1[0] * b2[2];
+        c->R[8] = b1[0] * b2[1] - b1[1] * b2[0];
     }
 }
 
@@ -127,7 +169,7 @@ static void rot_bwd(int rotfmt, const float *r, const rot_ctx *c, const float G[
         for (int i = 0; i < 3; ++i) wdotdw = fmaf(dw[i], c->w[i], wdotdw);
         dth -= wdotdw / th;                      /* d(r/theta)/dtheta = -r/theta^2 = -w/theta */
         for (int i = 0; i < 3; ++i) dr[i] = fmaf(dth, c->w[i], dw[i] / th);   /* dtheta/dr = r/theta = w */
-    } else {
+    } else if (rotfmt == NDP_ROT_EULER) {
         float dA[9], dMz[9], dMx[9], dMy[9];
         mat3_mul_nt(G, c->Mz, dA);
         mat3_mul_tn(c->A, G, dMz);
@@ -138,6 +180,54 @@ static void rot_bwd(int rotfmt, const float *r, const rot_ctx *c, const float G[
         dr[1] = (dMy[2] - dMy[6]) * k[1] - (dMy[0] + dMy[8]) * s[1];
         dr[2] = (dMz[3] - dMz[1]) * k[2] - (dMz[0] + dMz[4]) * s[2];
         (void)r;
+    } else if (rotfmt == NDP_ROT_QUATERNION) {
+        const float qr = c->q[0], qi = c->q[1], qj = c->q[2], qk = c->q[3], ts = c->ts;
+        /* R = I-part + ts * M(q);  dL/dts = <G, M> */
+        const float M[9] = {-(qj * qj + qk * qk), qi * qj - qk * qr, qi * qk + qj * qr,
+                            qi * qj + qk * qr, -(qi * qi + qk * qk), qj * qk - qi * qr,
+                            qi * qk - qj * qr, qj * qk + qi * qr, -(qi * qi + qj * qj)};
+        float dts = 0.f;
+        for (int i = 0; i < 9; ++i) dts = fmaf(G[i], M[i], dts);
+        float dq[4];
+        dq[0] = ts * (-qk * G[1] + qj * G[2] + qk * G[3] - qi * G[5] - qj * G[6] + qi * G[7]);
+        dq[1] = ts * (qj * G[1] + qk * G[2] + qj * G[3] - 2.f * qi * G[4] - qr * G[5] + qk * G[6] + qr * G[7] - 2.f * qi * G[8]);
+        dq[2] = ts * (-2.f * qj * G[0] + qi * G[1] + qr * G[2] + qi * G[3] + qk * G[5] - qr * G[6] + qk * G[7] - 2.f * qj * G[8]);
+        dq[3] = ts * (-2.f * qk * G[0] - qr * G[1] + qi * G[2] + qr * G[3] - 2.f * qk * G[4] + qj * G[5] + qi * G[6] + qj * G[7]);
+        /* ts = 2 / (q.q) */
+        float n2 = qr * qr;
+        n2 = fmaf(qi, qi, n2); n2 = fmaf(qj, qj, n2); n2 = fmaf(qk, qk, n2);
+        const float dn2 = dts * (-2.0f / (n2 * n2));
+        for (int i = 0; i < 4; ++i) dq[i] = fmaf(dn2, 2.0f * c->q[i], dq[i]);
+        /* q = r / d, d = sgn * sqrt(r.r)  =>  dr = (dq - (dq.q) q) / d */
+        float dot = 0.f;
+        for (int i = 0; i < 4; ++i) dot = fmaf(dq[i], c->q[i], dot);
+        for (int i = 0; i < 4; ++i) dr[i] = (dq[i] - dot * c->q[i]) / c->qd;
+        (void)r;
+    } else {
+        const float *b1 = c->b1, *b2 = c->b2;
+        const float *g1 = G, *g2 = G + 3, *g3 = G + 6;            /* dL/d(rows of R) */
+        /* b3 = b1 x b2 */
+        float db1[3] = {g1[0] + (b2[1] * g3[2] - b2[2] * g3[1]), g1[1] + (b2[2] * g3[0] - b2[0] * g3[2]),
+                        g1[2] + (b2[0] * g3[1] - b2[1] * g3[0])};
+        float db2[3] = {g2[0] + (g3[1] * b1[2] - g3[2] * b1[1]), g2[1] + (g3[2] * b1[0] - g3[0] * b1[2]),
+                        g2[2] + (g3[0] * b1[1] - g3[1] * b1[0])};
+        /* b2 = u / |u| */
+        float d2b = 0.f;
+        for (int i = 0; i < 3; ++i) d2b = fmaf(db2[i], b2[i], d2b);
+        float du[3];
+        for (int i = 0; i < 3; ++i) du[i] = (db2[i] - d2b * b2[i]) / c->nu;
+        /* u = a2 - (b1.a2) b1 */
+        float dub1 = 0.f;
+        for (int i = 0; i < 3; ++i) dub1 = fmaf(du[i], b1[i], dub1);
+        const float *a2 = r + 3;
+        for (int i = 0; i < 3; ++i) {
+            dr[3 + i] = du[i] - dub1 * b1[i];
+            db1[i] = db1[i] - c->cdot * du[i] - dub1 * a2[i];
+        }
+        /* b1 = a1 / |a1| */
+        float d1b = 0.f;
+        for (int i = 0; i < 3; ++i) d1b = fmaf(db1[i], b1[i], d1b);
+        for (int i = 0; i < 3; ++i) dr[i] = (db1[i] - d1b * b1[i]) / c->n1;
     }
 }
 

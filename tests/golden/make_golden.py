@@ -177,6 +177,9 @@ def F2_layer_forward(nets, **_):
         "sflow": dict(rotation_format="axis_angle", motion="sflow"),
         "se3eu": dict(rotation_format="euler", motion="SE3"),
         "sim3aa": dict(rotation_format="axis_angle", motion="Sim3"),
+        "se3quat": dict(rotation_format="quaternion", motion="SE3"),
+        "se36d": dict(rotation_format="6D", motion="SE3"),
+        "sim3quat": dict(rotation_format="quaternion", motion="Sim3"),
     }
     out["head_scale"] = np.float32(30.0)
     out["seed"] = np.int64(11)
