@@ -553,6 +553,8 @@ int ndp_o_optimize(const ndp_layer_desc *descs, const ndp_o_opt_cfg *cfg, float 
     float *grads = (float *)malloc(sizeof(float) * (size_t)maxP);
     float *am = (float *)malloc(sizeof(float) * (size_t)maxP);
     float *av = (float *)malloc(sizeof(float) * (size_t)maxP);
+    float *nrv = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    float *gnr = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     int total_steps = 0, ntrace = 0;
     size_t off = 0;
     for (int level = 0; level < cfg->m; ++level) {
@@ -564,7 +566,8 @@ int ndp_o_optimize(const ndp_layer_desc *descs, const ndp_o_opt_cfg *cfg, float 
         int break_counter = 0, t = 0, evals = 0;
         double loss_prev = 1e6;                       /* registration.py:179-180 */
         for (int it = 0; it < cfg->iters; ++it) {
-            ndp_o_level_fwd(d, params, level, cfg->k0, pts, n, warped, NULL, nthreads);   /* :208 */
+            const int use_reg = cfg->w_reg > 0.f && level > 0 && d->nonrigidity;          /* :216 */
+            ndp_o_level_fwd(d, params, level, cfg->k0, pts, n, warped, use_reg ? nrv : NULL, nthreads);   /* :208 */
             float loss = 0.f;
             if (K > 0) {
                 loss = ndp_o_landmark(warped, ldmk_t, K, g);                               /* :193,:203 */
@@ -581,13 +584,27 @@ int ndp_o_optimize(const ndp_layer_desc *descs, const ndp_o_opt_cfg *cfg, float 
             } else if (S > 0) {
                 memset(g + 3 * K, 0, sizeof(float) * 3 * (size_t)S);
             }
+            if (use_reg) {
+                /* registration.py:216-220: loss += w_reg * BCELoss(nonrigidity, 0), mean over all warped points;
+                 * torch clamps log at -100 and the backward divides by max((1-x) x, 1e-12)                    */
+                float acc = 0.f;
+                const float invn = 1.0f / (float)n;
+                for (int i = 0; i < n; ++i) {
+                    float l1 = logf(1.0f - nrv[i]);
+                    if (l1 < -100.0f) l1 = -100.0f;
+                    acc += -l1;
+                    const float den = (1.0f - nrv[i]) * nrv[i];
+                    gnr[i] = cfg->w_reg * (invn * (nrv[i] / (den > 1e-12f ? den : 1e-12f)));
+                }
+                loss = loss + cfg->w_reg * (acc * invn);
+            }
             ++evals;
             if (loss_trace && ntrace < trace_cap) loss_trace[ntrace++] = (double)loss;
             if (cfg->early_stop &&
                 ndp_o_stop_check((double)loss, &break_counter, &loss_prev, cfg->max_break_count,
                                  cfg->break_threshold_ratio))
                 break;
-            ndp_o_level_bwd(d, params, level, cfg->k0, pts, n, g, NULL, grads, nthreads); /* :236 */
+            ndp_o_level_bwd(d, params, level, cfg->k0, pts, n, g, use_reg ? gnr : NULL, grads, nthreads); /* :236 */
             ndp_o_adam(params, grads, am, av, P, ++t, cfg->lr, 0.9, 0.999, 1e-8);          /* :237 */
             ++total_steps;
         }
@@ -599,6 +616,6 @@ int ndp_o_optimize(const ndp_layer_desc *descs, const ndp_o_opt_cfg *cfg, float 
         off += (size_t)P;
     }
     free(warped); free(g); free(gcd); free(d2x); free(d2y); free(ix); free(iy);
-    free(grads); free(am); free(av);
+    free(grads); free(am); free(av); free(nrv); free(gnr);
     return total_steps;
 }

@@ -298,6 +298,81 @@ def F9_landmarks(nets, loss_mod, **_):
     save("F9_landmarks", **out)
 
 
+def F11_nonrigidity(nets, loss_mod, reg_mod, EasyDict, **_):
+    """w_reg > 0: the nonrigidity gate (nets.py:100-103,132-135) and the BCE regulariser (registration.py:216-220)."""
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(256, 3, generator=g) - 0.5
+    out["x"] = x.numpy()
+    out["seed"] = np.int64(13)
+    out["head_scale"] = np.float32(30.0)
+    for tag, kw in (("se3aa", dict(rotation_format="axis_angle", motion="SE3")),
+                    ("sim3quat", dict(rotation_format="quaternion", motion="Sim3")),
+                    ("sflow", dict(rotation_format="axis_angle", motion="sflow"))):
+        torch.manual_seed(13)
+        pyr = nets.Deformation_Pyramid(depth=3, width=128, device="cpu", k0=-8, m=6, nonrigidity_est=True, **kw)
+        lvl = 4
+        layer = pyr.pyramid[lvl]
+        with torch.no_grad():
+            for k, v in layer.named_parameters():
+                if "branch" in k or "brach" in k:
+                    v.mul_(30.0)
+        out[f"{tag}.wsum"] = np.float64(sum(v.double().abs().sum().item() for v in layer.parameters()))
+        y, data = pyr.warp(x, max_level=lvl, min_level=lvl)
+        nr = data[lvl][1]
+        out[f"{tag}.out"] = y.detach().numpy()
+        out[f"{tag}.nonrig"] = nr.detach().numpy()
+        coef = torch.linspace(-1.0, 1.0, 256 * 3).reshape(256, 3)
+        c2 = torch.linspace(0.5, -0.25, 256)
+        ((y * coef).sum() + (nr * c2).sum()).backward()
+        for k, v in layer.named_parameters():
+            out[f"{tag}.grad.{k}"] = v.grad.numpy().copy()
+        with torch.no_grad():
+            yfull, dfull = pyr.warp(x)
+        out[f"{tag}.full_out"] = yfull.numpy()
+        out[f"{tag}.level0_has_gate"] = np.bool_(data[lvl][1] is not None and pyr.pyramid[0].nonrigidity_est)
+    # iterations with the BCE term, exactly the loop body of registration.py:208-237 at level 2
+    torch.manual_seed(17)
+    pyr = nets.Deformation_Pyramid(depth=3, width=128, device="cpu", k0=-8, m=4, nonrigidity_est=True,
+                                   rotation_format="axis_angle", motion="SE3")
+    lvl, w_reg = 2, 0.5
+    g = torch.Generator().manual_seed(18)
+    xs = torch.rand(300, 3, generator=g) - 0.5
+    yt = (torch.rand(280, 3, generator=g) - 0.5) * 1.05 + 0.02
+    out["it.x"], out["it.y"], out["it.seed"], out["it.w_reg"] = xs.numpy(), yt.numpy(), np.int64(17), np.float32(w_reg)
+    layer = pyr.pyramid[lvl]
+    out["it.wsum"] = np.float64(sum(v.double().abs().sum().item() for v in layer.parameters()))
+    pyr.gradient_setup(optimized_level=lvl)
+    opt = torch.optim.Adam(layer.parameters(), lr=0.01)
+    BCE = torch.nn.BCELoss()
+    losses = []
+    for it in range(12):
+        w, data = pyr.warp(xs, max_level=lvl, min_level=lvl)
+        loss = loss_mod.compute_truncated_chamfer_distance(w[None], yt[None], trunc=1e9)
+        nonrigidity = data[lvl][1]
+        loss = loss + w_reg * BCE(nonrigidity, torch.zeros_like(nonrigidity))
+        losses.append(loss.item())
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            out["it.warp0"], out["it.nonrig0"] = w.detach().numpy().copy(), nonrigidity.detach().numpy().copy()
+            for k, v in layer.named_parameters():
+                out[f"it.grad0.{k}"] = v.grad.numpy().copy()
+        opt.step()
+        if it == 2:
+            for k, v in layer.named_parameters():
+                out[f"it.step3.{k}"] = v.detach().numpy().copy()
+    out["it.losses"] = np.array(losses, dtype=np.float64)
+    # end to end with w_reg > 0
+    src, tgt, flow_gt, overlap = synthetic_pair(11, n_total=2048)
+    cfg = ndp_config(EasyDict, samples=256, w_reg=0.3, m=5)
+    warped, trace = _register_traced(reg_mod, EasyDict, cfg, src, tgt, seed=4)
+    out["e2e.warped"] = warped.numpy()
+    out["e2e.iters_per_level"] = np.array([len(t) for t in trace])
+    out["e2e.loss_trace"] = np.array(sum(trace, []), dtype=np.float64)
+    save("F11_nonrigidity", **out)
+
+
 def _register_traced(reg_mod, EasyDict, cfg, src, tgt, landmarks=None, seed=0):
     """Run the reference's register() recording every loss it evaluates, per level."""
     trace = []
@@ -410,7 +485,7 @@ def main():
     todo = {
         "F1": F1_init, "F2": F2_layer_forward, "F3": F3_chamfer, "F4": F4_F5_iteration,
         "F7": F7_end_to_end, "F8": F8_metrics, "F9": F9_landmarks, "F9b": F9b_lndp_end_to_end,
-        "F10": F10_benchmark,
+        "F10": F10_benchmark, "F11": F11_nonrigidity,
     }
     only = [s for s in args.only.split(",") if s]
     for k, fn in todo.items():

@@ -214,3 +214,86 @@ def test_stop_rule_edges():
     # the counter is cumulative, never reset by a good step
     seq = [1.0] + [1.0] * 7 + [0.5] + [0.5] * 8
     assert O.stop_trace(seq)[0] == len(seq) - 1
+
+
+# ------------------------------------------------------------- F11: nonrigidity gate + BCE (w_reg > 0)
+F11_VARIANTS = {"se3aa": VARIANTS["se3aa"], "sim3quat": VARIANTS["sim3quat"], "sflow": VARIANTS["sflow"]}
+
+
+def _bce_zero_target(nr, w_reg):
+    """value and d/dnr of w_reg * BCELoss(nr, 0) with torch's clamps (registration.py:216-220)."""
+    nr = nr.astype(np.float32)
+    l1 = np.maximum(np.log(np.float32(1.0) - nr), np.float32(-100.0))
+    val = np.float32(w_reg) * np.float32((-l1).sum(dtype=np.float32) / np.float32(nr.size))
+    den = np.maximum((np.float32(1.0) - nr) * nr, np.float32(1e-12))
+    g = np.float32(w_reg) * (np.float32(1.0 / nr.size) * (nr / den))
+    return val, g.astype(np.float32)
+
+
+@pytest.mark.parametrize("tag", list(F11_VARIANTS))
+def test_F11_gate_forward_and_grads(golden, tag):
+    g = golden("F11_nonrigidity")
+    pyr = seeded_pyramid(int(g["seed"]), m=6, nonrigidity_est=True, **F11_VARIANTS[tag])
+    lvl = 4
+    assert not pyr.descs[0].nonrigidity and pyr.descs[lvl].nonrigidity            # nets.py:26: no gate at level 0
+    scale_heads(pyr, lvl, float(g["head_scale"]))
+    assert abs(wsum(pyr, lvl) - float(g[f"{tag}.wsum"])) < 1e-6 * float(g[f"{tag}.wsum"])
+    d = pyr.descs[lvl]
+    params = pyr.store[lvl, :d.param_count].numpy()
+    out, nr = O.level_fwd(cdesc(d), params, lvl, K0, g["x"], want_nonrig=True)
+    np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=0, atol=1e-5 if "quat" in tag else 2e-6)
+    np.testing.assert_allclose(nr, g[f"{tag}.nonrig"], rtol=0, atol=1e-6)
+    coef = torch.linspace(-1.0, 1.0, 256 * 3).reshape(256, 3).numpy()
+    c2 = torch.linspace(0.5, -0.25, 256).numpy()
+    grads = O.level_bwd(cdesc(d), params, lvl, K0, g["x"], coef, g_nr=c2)
+    for name, off, shape in d.named_slices():
+        ref = g[f"{tag}.grad.{name}"]
+        got = grads[off:off + ref.size].reshape(ref.shape)
+        assert rel_err(got, ref) < 1e-4, (tag, name, rel_err(got, ref))
+    descs = [cdesc(x) for x in pyr.descs]
+    params_all = np.concatenate([pyr.store[i, :x.param_count].numpy() for i, x in enumerate(pyr.descs)])
+    full = O.pyramid_fwd(descs, K0, params_all, g["x"])
+    np.testing.assert_allclose(full, g[f"{tag}.full_out"], rtol=0, atol=2e-5)
+
+
+def test_F11_iterations_with_bce(golden):
+    g = golden("F11_nonrigidity")
+    pyr = seeded_pyramid(int(g["it.seed"]), m=4, nonrigidity_est=True, **VARIANTS["se3aa"])
+    lvl, w_reg = 2, float(g["it.w_reg"])
+    assert abs(wsum(pyr, lvl) - float(g["it.wsum"])) < 1e-6 * float(g["it.wsum"])
+    d = pyr.descs[lvl]
+    cd = cdesc(d)
+    p = pyr.store[lvl, :d.param_count].numpy().copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    losses = []
+    for it in range(12):
+        w, nr = O.level_fwd(cd, p, lvl, K0, g["it.x"], want_nonrig=True)
+        r = O.chamfer(w, g["it.y"])
+        reg, gnr = _bce_zero_target(nr, w_reg)
+        losses.append(float(np.float32(r["loss"]) + reg))
+        grads = O.level_bwd(cd, p, lvl, K0, g["it.x"], r["gx"], g_nr=gnr)
+        if it == 0:
+            np.testing.assert_allclose(w, g["it.warp0"], rtol=0, atol=1e-6)
+            np.testing.assert_allclose(nr, g["it.nonrig0"], rtol=0, atol=1e-6)
+            for name, off, shape in d.named_slices():
+                ref = g[f"it.grad0.{name}"]
+                assert rel_err(grads[off:off + ref.size].reshape(ref.shape), ref) < 1e-4, name
+        O.adam(p, grads, m, v, it + 1)
+    ref = g["it.losses"]
+    assert abs(losses[0] - ref[0]) < 2e-6 * ref[0]
+    assert np.abs(np.array(losses) - ref).max() < 1e-2 * ref.max()
+
+
+def test_F11_oracle_level_loop_matches_hand_rolled_bce(golden):
+    """ndp_o_optimize with w_reg > 0 equals the step-by-step composition above (same C pieces)."""
+    g = golden("F11_nonrigidity")
+    pyr = seeded_pyramid(int(g["it.seed"]), m=3, nonrigidity_est=True, **VARIANTS["se3aa"])
+    descs = [cdesc(x) for x in pyr.descs]
+    params_all = np.concatenate([pyr.store[i, :x.param_count].numpy() for i, x in enumerate(pyr.descs)])
+    r = O.optimize(descs, params_all, g["it.x"], 0, g["it.x"].shape[0], None, g["it.y"], iters=4, early_stop=False, w_reg=0.5)
+    assert r["steps"] == 12 and list(r["iters_per_level"]) == [4, 4, 4]
+    # level 0 carries no gate: its first loss is the plain Chamfer value
+    w0 = O.level_fwd(descs[0], params_all[:pyr.descs[0].param_count], 0, K0, g["it.x"])
+    assert abs(r["loss_trace"][0] - float(O.chamfer(w0, g["it.y"])["loss"])) < 1e-7
+    # at level 1 the BCE term is present (loss > Chamfer alone)
+    assert r["loss_trace"][4] > 0.5 * 0.6                        # w_reg * -log(1 - 0.5) = 0.35 at init, plus Chamfer
