@@ -51,7 +51,7 @@ class Engine(ctypes.Structure):
                 ("break_threshold_ratio", ctypes.c_double),
                 ("w_cd", ctypes.c_float), ("trunc", ctypes.c_float),
                 ("adam_w1", ctypes.c_float), ("adam_b2", ctypes.c_float), ("adam_w2", ctypes.c_float),
-                ("adam_eps", ctypes.c_float),
+                ("adam_eps", ctypes.c_float), ("w_reg", ctypes.c_float), ("pad_f", ctypes.c_float),
                 ("geom", ctypes.c_void_p), ("state", ctypes.c_void_p), ("pts", ctypes.c_void_p),
                 ("ldmk_t", ctypes.c_void_p), ("tgt", ctypes.c_void_p), ("params", ctypes.c_void_p),
                 ("gpart", ctypes.c_void_p), ("adam_m", ctypes.c_void_p), ("adam_v", ctypes.c_void_p),
@@ -92,8 +92,8 @@ F = ctypes.c_float
 DP = ctypes.POINTER(CLayerDesc)
 
 _SIGS = {
-    "ndp_level_fwd": [DP, V, I, I, V, I, V, V, V, V],
-    "ndp_level_bwd": [DP, V, I, I, V, I, V, V, V, V, V, I, I, V],
+    "ndp_level_fwd": [DP, V, I, I, V, I, V, V, V, V, V],
+    "ndp_level_bwd": [DP, V, I, I, V, I, V, V, V, V, V, V, I, I, V],
     "ndp_grad_reduce": [V, I, I, I, V, V],
     "ndp_pyramid_fwd": [DP, I, I, V, I, V, I, V, V, V],
     "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],

@@ -20,6 +20,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct HeadCfg {
     int motion, rotfmt, n_rot, row_scale, row_trn, nh;
+    int nonrig, row_nr;          // nonrigidity gate head present (nets.py:100-103) and its row
     float mlp_scale;
 };
 
@@ -31,8 +32,18 @@ __host__ __device__ inline HeadCfg make_head_cfg(const ndp_layer_desc &d) {
     h.row_scale = ndp_head_row_scale(&d);
     h.row_trn = ndp_head_row_trn(&d);
     h.nh = ndp_n_heads(&d);
+    h.nonrig = d.nonrigidity ? 1 : 0;
+    h.row_nr = ndp_head_row_nr(&d);
     h.mlp_scale = d.mlp_scale;
     return h;
+}
+
+// Engine / pyramid descriptors carry nonrigidity = 1 to mean "every level but the first has the gate"
+// (Deformation_Pyramid builds level i with nonrigidity_est & (i != 0), nets.py:26).
+__host__ __device__ inline ndp_layer_desc desc_at_level(const ndp_layer_desc &d, int level) {
+    ndp_layer_desc r = d;
+    r.nonrigidity = (d.nonrigidity && level > 0) ? 1 : 0;
+    return r;
 }
 
 __device__ __forceinline__ void mat3_mul(const float *A, const float *B, float *C) {
@@ -77,6 +88,7 @@ struct PointHead {
     float q[4], qd, ts;                              // quaternion
     float b1[3], b2[3], n1, nu, cdot;                // 6D
     float rx[3], s;
+    float nr, xw[3];                                 // gate value and the warp before gating
 };
 
 __device__ __forceinline__ void rot_fwd(int rotfmt, const float *r, PointHead &c) {
@@ -247,43 +259,61 @@ __device__ __forceinline__ void rot_bwd(int rotfmt, const float *r, const PointH
     }
 }
 
-// o: scaled head outputs (rot.., scale, trn).  x -> out.   nets.py:117-129
+// o: scaled head outputs (rot.., scale, trn, nr).  x -> out.   nets.py:117-135
 __device__ __forceinline__ void head_warp_fwd(const HeadCfg &hc, const float *o, const float *x,
                                               PointHead &c, float *out) {
     const float *t = o + hc.row_trn;
     if (hc.motion == NDP_MOTION_SFLOW) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a) out[a] = x[a] + t[a];
-        return;
-    }
-    rot_fwd(hc.rotfmt, o, c);
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        float s = c.R[a * 3] * x[0];
-        s = fmaf(c.R[a * 3 + 1], x[1], s);
-        s = fmaf(c.R[a * 3 + 2], x[2], s);
-        c.rx[a] = s;
-    }
-    if (hc.motion == NDP_MOTION_SIM3) {
-        c.s = o[hc.row_scale] + 1.0f;
-#pragma unroll
-        for (int a = 0; a < 3; ++a) out[a] = fmaf(c.s, c.rx[a], t[a]);
+        for (int a = 0; a < 3; ++a) c.xw[a] = x[a] + t[a];
     } else {
+        rot_fwd(hc.rotfmt, o, c);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) out[a] = c.rx[a] + t[a];
+        for (int a = 0; a < 3; ++a) {
+            float s = c.R[a * 3] * x[0];
+            s = fmaf(c.R[a * 3 + 1], x[1], s);
+            s = fmaf(c.R[a * 3 + 2], x[2], s);
+            c.rx[a] = s;
+        }
+        if (hc.motion == NDP_MOTION_SIM3) {
+            c.s = o[hc.row_scale] + 1.0f;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) c.xw[a] = fmaf(c.s, c.rx[a], t[a]);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) c.xw[a] = c.rx[a] + t[a];
+        }
+    }
+    if (hc.nonrig) {                                  // nets.py:132-135
+        c.nr = 1.0f / (1.0f + expf(-o[hc.row_nr]));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) out[a] = fmaf(c.nr, c.xw[a] - x[a], x[a]);
+    } else {
+        c.nr = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) out[a] = c.xw[a];
     }
 }
 
 // g = dL/dout -> d_o = dL/d(scaled head outputs).  d_o points at NDP_NHMAX floats in LDS (rows are
 // addressed with run-time offsets, which registers cannot do); unused rows are zeroed.
 __device__ __forceinline__ void head_warp_bwd(const HeadCfg &hc, const float *x, const PointHead &c,
-                                              const float *g, float *d_o) {
+                                              const float *g_in, float g_nr, float *d_o) {
     // the 6D backward needs the raw rot outputs: read them before the row is reused for the gradient
     float rraw[6];
 #pragma unroll
     for (int a = 0; a < 6; ++a) rraw[a] = d_o[a];
 #pragma unroll
     for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(d_o + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    float g[3] = {g_in[0], g_in[1], g_in[2]};
+    if (hc.nonrig) {
+        float dnr = g_nr;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dnr = fmaf(g[a], c.xw[a] - x[a], dnr);
+        d_o[hc.row_nr] = dnr * (c.nr * (1.0f - c.nr));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) g[a] *= c.nr;
+    }
 #pragma unroll
     for (int a = 0; a < 3; ++a) d_o[hc.row_trn + a] = g[a];
     if (hc.motion == NDP_MOTION_SFLOW) return;
@@ -327,14 +357,15 @@ __device__ __forceinline__ float block_sum_256(float v, float *scratch /* >= 256
 // outputs, push g = dL/dx_out through it, and emit dO = mlp_scale * dL/d(scaled outputs) (16 floats).
 // lds_row: NDP_NHMAX floats of LDS private to the calling thread (run-time row offsets live there).
 __device__ __forceinline__ void point_head_bwd(const HeadCfg &hc, const float *heads_row /*global, NDP_HROW*/,
-                                               const float *x, const float *g, float *lds_row, float *dO_row /*global*/) {
+                                               const float *x, const float *g, float g_nr, float *lds_row,
+                                               float *dO_row /*global*/) {
 #pragma unroll
     for (int j = 0; j < NDP_NHMAX; j += 4)
         *reinterpret_cast<float4 *>(lds_row + j) = *reinterpret_cast<const float4 *>(heads_row + j);
     PointHead c;
     float out[3];
     head_warp_fwd(hc, lds_row, x, c, out);
-    head_warp_bwd(hc, x, c, g, lds_row);
+    head_warp_bwd(hc, x, c, g, g_nr, lds_row);
 #pragma unroll
     for (int j = 0; j < NDP_NHMAX; j += 4) {
         float4 v = *reinterpret_cast<const float4 *>(lds_row + j);

@@ -52,6 +52,7 @@ struct LevelJob {
     float *x_out;
     float *act;        // [3][plane][128] or nullptr
     float *heads;      // [plane][NDP_HROW] or nullptr: 16 scaled head outputs + 6 posenc values
+    float *nonrig;     // [n] or nullptr: gate value per point (levels with the nonrigidity head)
     int n;             // live points
     int plane;         // rows per activation plane (capacity, multiple of 64)
     int n_tiles;       // live tiles = ceil(n / 64)
@@ -263,6 +264,7 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
                 float out[3];
                 head_warp_fwd(hc, o, xs + 4 * t, c, out);
                 job.x_out[3 * p] = out[0]; job.x_out[3 * p + 1] = out[1]; job.x_out[3 * p + 2] = out[2];
+                if (job.nonrig) job.nonrig[p] = c.nr;
             }
         }
         __syncthreads();
@@ -578,7 +580,7 @@ k_level_bwd1(HeadCfg hc, BwdJob job, int p_stride) {
 
 // dO[p][16] = mlp_scale * dL/d(scaled head outputs) for p < n, zero rows up to `plane`
 extern "C" __global__ void __launch_bounds__(256)
-k_head_bwd(HeadCfg hc, const float *x, const float *heads, const float *g, int n, int plane, float *dO) {
+k_head_bwd(HeadCfg hc, const float *x, const float *heads, const float *g, const float *g_nr, int n, int plane, float *dO) {
     __shared__ __attribute__((aligned(16))) float rows[256 * NDP_NHMAX];
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= plane) return;
@@ -586,7 +588,7 @@ k_head_bwd(HeadCfg hc, const float *x, const float *heads, const float *g, int n
     if (p < n) {
         const float xv[3] = {x[3 * p], x[3 * p + 1], x[3 * p + 2]};
         const float gv[3] = {g[3 * p], g[3 * p + 1], g[3 * p + 2]};
-        point_head_bwd(hc, heads + (size_t)p * NDP_HROW, xv, gv, rows + threadIdx.x * NDP_NHMAX, out);
+        point_head_bwd(hc, heads + (size_t)p * NDP_HROW, xv, gv, g_nr ? g_nr[p] : 0.f, rows + threadIdx.x * NDP_NHMAX, out);
     } else {
 #pragma unroll
         for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(out + j) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -804,9 +806,10 @@ k_eng_fwd(ndp_engine e, int parity) {
     job.n = gm.K + gm.S;
     job.n_tiles = (job.n + NDP_TILE - 1) / NDP_TILE;
     if ((int)blockIdx.x >= job.n_tiles) return;
-    const HeadCfg hc = make_head_cfg(e.desc);
+    const HeadCfg hc = make_head_cfg(desc_at_level(e.desc, st.level));
     job.params = e.params + ((size_t)b * e.m + st.level) * e.p_stride;
     job.freq = level_freq(st.level, e.k0);
+    job.nonrig = nullptr;
     float *pts = e.pts + (size_t)b * 2 * e.n_cap * 3;
     job.x_in = pts + (size_t)st.cur * e.n_cap * 3;
     job.x_out = pts + (size_t)(st.cur ^ 1) * e.n_cap * 3;
@@ -872,6 +875,9 @@ k_eng_loss(ndp_engine e, int parity) {
     const float *d2x = e.d2x + (size_t)b * e.n_cap, *d2y = e.d2y + (size_t)b * e.t_cap;
     const int *idx_x = e.idx_x + (size_t)b * e.n_cap, *idx_y = e.idx_y + (size_t)b * e.t_cap;
     const bool use_cd = gm.S > 0 && e.w_cd != 0.f;
+    const HeadCfg hcl = make_head_cfg(desc_at_level(e.desc, st.level));
+    const bool use_reg = e.w_reg > 0.f && hcl.nonrig;
+    const float *hrec = e.heads + (size_t)b * e.n_cap * NDP_HROW;
 
     if (blockIdx.x == 0) {
         float loss = 0.f;
@@ -881,6 +887,17 @@ k_eng_loss(ndp_engine e, int parity) {
             const float sy = l1_sum(d2y, gm.T, e.trunc, red);
             const float lcd = sx / (float)gm.S + sy / (float)gm.T;
             loss = gm.K > 0 ? loss + e.w_cd * lcd : lcd;
+        }
+        if (use_reg) {                                   // registration.py:216-220: + w_reg * BCELoss(nonrigidity, 0)
+            float acc = 0.f;
+            for (int i = t; i < n; i += 256) {
+                const float nr = 1.0f / (1.0f + expf(-hrec[(size_t)i * NDP_HROW + hcl.row_nr]));
+                float l1 = logf(1.0f - nr);
+                if (l1 < -100.0f) l1 = -100.0f;
+                acc += -l1;
+            }
+            acc = block_sum_256(acc, red);
+            loss = loss + e.w_reg * (acc * (1.0f / (float)n));
         }
         if (t == 0) {
             int bc = st.break_counter;
@@ -1021,8 +1038,13 @@ k_eng_loss(ndp_engine e, int parity) {
     if (p < n) {
         const float *xin = e.pts + ((size_t)b * 2 + st.cur) * e.n_cap * 3 + 3 * p;
         const float xv[3] = {xin[0], xin[1], xin[2]};
-        const HeadCfg hc = make_head_cfg(e.desc);
-        point_head_bwd(hc, e.heads + ((size_t)b * e.n_cap + p) * NDP_HROW, xv, g, rows + t * NDP_NHMAX, dO_row);
+        float g_nr = 0.f;
+        if (use_reg) {                                   // d/dnr of w_reg * mean(-log(1 - nr)), torch's BCE backward clamp
+            const float nr = 1.0f / (1.0f + expf(-hrec[(size_t)p * NDP_HROW + hcl.row_nr]));
+            const float den = (1.0f - nr) * nr;
+            g_nr = e.w_reg * ((1.0f / (float)n) * (nr / (den > 1e-12f ? den : 1e-12f)));
+        }
+        point_head_bwd(hcl, hrec + (size_t)p * NDP_HROW, xv, g, g_nr, rows + t * NDP_NHMAX, dO_row);
     } else if (p < e.n_cap) {
 #pragma unroll
         for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(dO_row + j) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1057,7 +1079,7 @@ k_eng_bwdh(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, true)) return;
-    bwdh_body(make_head_cfg(e.desc), job, sm);
+    bwdh_body(make_head_cfg(desc_at_level(e.desc, e.state[(size_t)(parity ^ 1) * e.B + blockIdx.y].step_level)), job, sm);
 }
 
 extern "C" __global__ void __launch_bounds__(256, 2)
@@ -1065,7 +1087,7 @@ k_eng_bwd2(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, false)) return;
-    bwd2_body(make_head_cfg(e.desc), job, sm);
+    bwd2_body(make_head_cfg(desc_at_level(e.desc, 0)), job, sm);
 }
 
 extern "C" __global__ void __launch_bounds__(256, 2)
@@ -1073,7 +1095,7 @@ k_eng_bwd1(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, false)) return;
-    bwd1_body(make_head_cfg(e.desc), job, sm);
+    bwd1_body(make_head_cfg(desc_at_level(e.desc, 0)), job, sm);
 }
 
 // fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state)
@@ -1083,8 +1105,13 @@ k_eng_update(ndp_engine e, int parity) {
     const ndp_pair_state ns = e.state[(size_t)(parity ^ 1) * e.B + b];      // written by k_eng_bwd this tick
     if (ns.decision == NDP_DEC_IDLE) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const ndp_layer_desc dl = desc_at_level(e.desc, ns.step_level);
     if (i >= e.P) return;
     float *m = e.adam_m + (size_t)b * e.p_stride, *v = e.adam_v + (size_t)b * e.p_stride;
+    if (i >= ndp_param_count(&dl)) {                     // level 0 has no gate row: nothing to step, keep moments clean
+        if (ns.decision != NDP_DEC_STEP) { m[i] = 0.f; v[i] = 0.f; }
+        return;
+    }
     if (ns.decision != NDP_DEC_ADVANCE) {
         const float *gp = e.gpart + (size_t)b * e.G * e.p_stride;
         float g = gp[i];
@@ -1120,7 +1147,6 @@ static int check_desc(const ndp_layer_desc *d) {
     if (!d) return fail(NDP_E_INVALID, "null layer descriptor");
     if (d->width != NDP_W || d->n_hidden != 2)
         return fail(NDP_E_UNSUPPORTED, "kernels are specialised for width=128, depth=3");
-    if (d->nonrigidity) return fail(NDP_E_UNSUPPORTED, "nonrigidity gate (w_reg > 0) not implemented in the HIP path yet");
     if (d->motion < 0 || d->motion > 2) return fail(NDP_E_INVALID, "bad motion type");
     if (d->motion != NDP_MOTION_SFLOW && (d->rotfmt < NDP_ROT_AXIS_ANGLE || d->rotfmt > NDP_ROT_6D))
         return fail(NDP_E_INVALID, "bad rotation_format");
@@ -1140,7 +1166,8 @@ extern "C" int ndp_version(void) { return 100; }
 extern "C" const char *ndp_last_error(void) { return g_err; }
 
 extern "C" int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
-                             const float *x, int n, float *x_out, float *act, float *heads, void *stream) {
+                             const float *x, int n, float *x_out, float *act, float *heads, float *nonrig_out,
+                             void *stream) {
     if (int rc = check_desc(desc)) return rc;
     if (n < 0 || !params || (n > 0 && (!x || !x_out))) return fail(NDP_E_INVALID, "ndp_level_fwd: null pointer / negative n");
     if (!aligned16(params) || (act && !aligned16(act)) || (heads && !aligned16(heads)))
@@ -1149,6 +1176,7 @@ extern "C" int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, in
     LevelJob job;
     job.params = params; job.freq = ldexpf(1.0f, level + 1 + k0);
     job.x_in = x; job.x_out = x_out; job.act = act; job.heads = heads;
+    job.nonrig = desc->nonrigidity ? nonrig_out : nullptr;
     job.n = n; job.n_tiles = (n + NDP_TILE - 1) / NDP_TILE; job.plane = job.n_tiles * NDP_TILE;
     job.tile0 = 0; job.tile_step = 0;
     if (int rc = set_smem((const void *)k_level_fwd, kSmemFwdBytes)) return rc;
@@ -1161,8 +1189,8 @@ extern "C" int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, in
 }
 
 extern "C" int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
-                             const float *x, int n, float *act, const float *heads, const float *g, float *dO_work,
-                             float *grads_part, int n_part, int p_stride, void *stream) {
+                             const float *x, int n, float *act, const float *heads, const float *g, const float *g_nr,
+                             float *dO_work, float *grads_part, int n_part, int p_stride, void *stream) {
     (void)level; (void)k0;
     if (int rc = check_desc(desc)) return rc;
     if (n <= 0 || !params || !x || !act || !heads || !g || !dO_work || !grads_part || n_part < 1)
@@ -1185,7 +1213,8 @@ extern "C" int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, in
     if (int rc = set_smem((const void *)k_level_bwdh, kSmemBwdHBytes)) return rc;
     if (int rc = set_smem((const void *)k_level_bwd1, kSmemBwdBytes)) return rc;
     const HeadCfg hc = make_head_cfg(*desc);
-    hipLaunchKernelGGL(k_head_bwd, dim3((job.plane + 255) / 256), dim3(256), 0, s, hc, x, heads, g, n, job.plane, dO_work);
+    hipLaunchKernelGGL(k_head_bwd, dim3((job.plane + 255) / 256), dim3(256), 0, s, hc, x, heads, g,
+                       desc->nonrigidity ? g_nr : nullptr, n, job.plane, dO_work);
     hipLaunchKernelGGL(k_level_bwdh, dim3(n_part), dim3(256), kSmemBwdHBytes, s, hc, job, p_stride);
     hipLaunchKernelGGL(k_level_bwd2, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
     hipLaunchKernelGGL(k_level_bwd1, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
@@ -1213,7 +1242,8 @@ extern "C" int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const 
     const float *src = x;
     for (int l = 0; l < m; ++l) {
         float *dst = ((m - 1 - l) % 2 == 0) ? x_out : tmp;
-        if (int rc = ndp_level_fwd(desc, params_all + (size_t)l * p_stride, l, k0, src, n, dst, nullptr, nullptr, stream)) return rc;
+        const ndp_layer_desc dl = desc_at_level(*desc, l);       // desc->nonrigidity = "levels > 0 carry the gate"
+        if (int rc = ndp_level_fwd(&dl, params_all + (size_t)l * p_stride, l, k0, src, n, dst, nullptr, nullptr, nullptr, stream)) return rc;
         src = dst;
     }
     return 0;

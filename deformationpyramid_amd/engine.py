@@ -30,13 +30,14 @@ class OptConfig:
     break_threshold_ratio: float = 0.001
     w_cd: float = 1.0          # weight of the Chamfer term (1 without landmarks; config.w_cd with)
     trunc: float = 1e9         # truncation in squared units (registration.py:212 / config.trunc_cd)
+    w_reg: float = 0.0         # nonrigidity BCE weight (registration.py:216-220); needs desc.nonrigidity
     early_stop: bool = True
 
 
 class BatchedEngine:
     def __init__(self, desc: LayerDesc, cfg: OptConfig, B: int, n_cap: int, t_cap: int, device, G=None):
-        if desc.nonrigidity:
-            raise N.NdpError("nonrigidity gate (w_reg > 0) is not implemented in the HIP path")
+        # desc.nonrigidity = True means "every level but the first carries the gate" (nets.py:26); P is then the
+        # parameter count of a gated level and level 0 uses a prefix-compatible shorter layout.
         self.lib = N.lib()
         self.desc, self.cfg, self.B = desc, cfg, B
         self.device = torch.device(device)
@@ -86,6 +87,7 @@ class BatchedEngine:
         e.B, e.G, e.n_cap, e.t_cap = self.B, self.G, self.n_cap, self.t_cap
         e.break_threshold_ratio = c.break_threshold_ratio
         e.w_cd, e.trunc = c.w_cd, c.trunc
+        e.w_reg = c.w_reg if self.desc.nonrigidity else 0.0
         e.adam_w1, e.adam_b2, e.adam_w2, e.adam_eps = 1 - 0.9, 0.999, 1 - 0.999, 1e-8
         for name in ("geom", "state", "pts", "ldmk_t", "tgt", "params", "gpart", "adam_m", "adam_v", "act", "heads",
                      "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "dO"):

@@ -34,25 +34,33 @@ def cap(n):
     return max(TILE, (n + TILE - 1) // TILE * TILE)
 
 
-def level_fwd(desc: LayerDesc, params, level, k0, x, save=False):
-    """x [n,3] -> x_out [n,3] (+ (act [3,cap,128], heads [cap,16]) when save)."""
+def level_fwd(desc: LayerDesc, params, level, k0, x, save=False, want_nonrig=False):
+    """x [n,3] -> x_out [n,3]; with save also (act [3,cap,128], heads [cap,24]); with want_nonrig the gate
+    values [n] of a level that carries the nonrigidity head are appended."""
     _chk(params, "params"); _chk(x, "x")
     n = x.shape[0]
     out = torch.empty_like(x)
-    act = heads = None
+    act = heads = nr = None
     if save:
         c = cap(n)
         act = torch.empty(3, c, 128, device=x.device, dtype=torch.float32)
         heads = torch.empty(c, N.HROW, device=x.device, dtype=torch.float32)
+    if want_nonrig and desc.nonrigidity:
+        nr = torch.empty(n, device=x.device, dtype=torch.float32)
     cd = desc.c_struct()
     N.check(N.lib().ndp_level_fwd(ctypes.byref(cd), _p(params), int(level), int(k0), _p(x), n, _p(out),
-                                  _p(act), _p(heads), N.stream_ptr(x.device)), "ndp_level_fwd")
-    return (out, act, heads) if save else out
+                                  _p(act), _p(heads), _p(nr), N.stream_ptr(x.device)), "ndp_level_fwd")
+    res = (out, act, heads) if save else (out,)
+    if want_nonrig:
+        res = res + (nr,)
+    return res if len(res) > 1 else res[0]
 
 
-def level_bwd(desc: LayerDesc, params, level, k0, x, act, heads, g, n_part=None):
+def level_bwd(desc: LayerDesc, params, level, k0, x, act, heads, g, n_part=None, g_nr=None):
     """-> grads [P] (partials folded in index order on the device).  `act` is consumed."""
     _chk(params, "params"); _chk(x, "x"); _chk(act, "act"); _chk(heads, "heads"); _chk(g, "g")
+    if g_nr is not None:
+        _chk(g_nr, "g_nr")
     n = x.shape[0]
     P = desc.param_count
     stride = (P + 3) // 4 * 4
@@ -64,7 +72,7 @@ def level_bwd(desc: LayerDesc, params, level, k0, x, act, heads, g, n_part=None)
     cd = desc.c_struct()
     st = N.stream_ptr(x.device)
     N.check(N.lib().ndp_level_bwd(ctypes.byref(cd), _p(params), int(level), int(k0), _p(x), n, _p(act), _p(heads),
-                                  _p(g), _p(work), _p(part), n_part, stride, st), "ndp_level_bwd")
+                                  _p(g), _p(g_nr), _p(work), _p(part), n_part, stride, st), "ndp_level_bwd")
     grads = torch.empty(P, device=x.device, dtype=torch.float32)
     N.check(N.lib().ndp_grad_reduce(_p(part), n_part, stride, P, _p(grads), st), "ndp_grad_reduce")
     return grads
@@ -130,25 +138,33 @@ def adam_step(p, g, m, v, t, lr=0.01, b1=0.9, b2=0.999, eps=1e-8):
 # ------------------------------------------------------------------------------ autograd wrappers
 class _LevelWarpFn(torch.autograd.Function):
     """NDPLayer.forward (nets.py:111-140) for callers that own their optimisation loop
-    (shape_transfer.py:116-157).  x is treated as detached, as on the reference's hot path."""
+    (shape_transfer.py:116-157).  x is treated as detached, as on the reference's hot path.
+    Returns (x', nonrigidity) -- the gate tensor is empty for levels without the nonrigidity head."""
 
     @staticmethod
     def forward(ctx, x, layer, *params):
         need = any(p.requires_grad for p in params)
         flat = layer.flat.detach()
+        xd = x.detach().contiguous()
+        gate = layer.desc.nonrigidity
         if need:
-            out, act, heads = level_fwd(layer.desc, flat, layer.level, layer.k0, x.detach().contiguous(), save=True)
-            ctx.save_for_backward(x.detach().contiguous(), act, heads)
+            res = level_fwd(layer.desc, flat, layer.level, layer.k0, xd, save=True, want_nonrig=True)
+            out, act, heads, nr = res
+            ctx.save_for_backward(xd, act, heads)
             ctx.layer = layer
         else:
-            out = level_fwd(layer.desc, flat, layer.level, layer.k0, x.detach().contiguous())
-        return out
+            out, nr = level_fwd(layer.desc, flat, layer.level, layer.k0, xd, want_nonrig=True)
+        if not gate:
+            nr = torch.empty(0, device=x.device)
+            ctx.mark_non_differentiable(nr)
+        return out, nr
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_nr):
         x, act, heads = ctx.saved_tensors
         layer = ctx.layer
-        grads = level_bwd(layer.desc, layer.flat.detach(), layer.level, layer.k0, x, act, heads, g.contiguous())
+        gnr = g_nr.contiguous() if (layer.desc.nonrigidity and g_nr is not None) else None
+        grads = level_bwd(layer.desc, layer.flat.detach(), layer.level, layer.k0, x, act, heads, g.contiguous(), g_nr=gnr)
         outs = []
         for name, off, shape in layer.desc.named_slices():
             n = 1
@@ -159,13 +175,12 @@ class _LevelWarpFn(torch.autograd.Function):
 
 
 def level_warp(layer, x):
-    """-> (x', nonrigidity=None).  Squeeze semantics of nets.py:140 are not reproduced (n >= 2)."""
-    if layer.desc.nonrigidity:
-        raise N.NdpError("nonrigidity gate (w_reg > 0) is not implemented in the HIP path")
+    """-> (x', nonrigidity | None).  Squeeze semantics of nets.py:140 are not reproduced (n >= 2)."""
     if x.dim() != 2 or x.shape[-1] != 3:
         raise ValueError("expected points of shape [n, 3]")
     params = tuple(layer.parameters())
-    return _LevelWarpFn.apply(x.float(), layer, *params), None
+    out, nr = _LevelWarpFn.apply(x.float(), layer, *params)
+    return out, (nr if layer.desc.nonrigidity else None)
 
 
 class _ChamferFn(torch.autograd.Function):

@@ -217,14 +217,13 @@ class Registration:
 
     def _opt_config(self, has_ldmk):
         c = self.config
-        if c.w_reg > 0:
-            raise N.NdpError("w_reg > 0 (nonrigidity gate + BCE regulariser) is not implemented in the HIP path")
         if has_ldmk:
             w_cd, trunc = float(c.w_cd), float(c.trunc_cd)                       # registration.py:189-197
         else:
             w_cd, trunc = 1.0, 1e9                                               # registration.py:212
         return OptConfig(m=c.m, k0=c.k0, iters=c.iters, lr=c.lr, max_break_count=c.max_break_count,
-                         break_threshold_ratio=c.break_threshold_ratio, w_cd=w_cd, trunc=trunc, early_stop=True)
+                         break_threshold_ratio=c.break_threshold_ratio, w_cd=w_cd, trunc=trunc,
+                         w_reg=float(c.w_reg), early_stop=True)
 
     def _prepare(self, src_pcd, tgt_pcd, landmarks):
         c = self.config
@@ -233,10 +232,13 @@ class Registration:
             raise N.NdpError("the HIP kernels are specialised for depth=3, width=128 (NDP.yaml / LNDP.yaml)")
         p = _Prepared()
         # registration.py:133-140 -- all m levels are initialised up front on the CPU generator
-        p.desc = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format)
+        gate = c.w_reg > 0                                                          # registration.py:138
+        p.desc = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format,
+                           nonrigidity=gate)                                        # engine: "levels > 0 gated"
+        level0 = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format)
         stride = (p.desc.param_count + 63) // 64 * 64
         host = self._pinned_store(c.m, stride)                                     # reused pinned staging buffer
-        init_pyramid_store([p.desc] * c.m, c.depth, stride, out=host)
+        init_pyramid_store([level0] + [p.desc] * (c.m - 1), c.depth, stride, out=host)   # nets.py:26
         p.store = host.to(dev, non_blocking=True)                                  # async upload on the current stream
         self._pin_busy.append((host, torch.cuda.Event()))
         self._pin_busy[-1][1].record(torch.cuda.current_stream(dev))

@@ -39,24 +39,28 @@ const char *ndp_last_error(void);      /* text of the last non-zero return on th
  *   act  (may be NULL): [3][n_cap][128] saved post-ReLU activations h0,h1,h2 for ndp_level_bwd
  *   heads(may be NULL): [n_cap][NDP_HROW] per-point record: 16 scaled head outputs (rot.., scale,
  *                       trn, nr) followed by the 6 positional-encoding values and 2 pad floats
+ *   nonrig_out (may be NULL): [n] gate values sigmoid(0.001 nr_branch(h)) when desc->nonrigidity
+ *                       (the second element NDPLayer.forward returns, nets.py:133-140)
  * n_cap = n rounded up to NDP_TILE (row count of act/heads).                                   */
 int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
-                  const float *x, int n, float *x_out, float *act, float *heads, void *stream);
+                  const float *x, int n, float *x_out, float *act, float *heads, float *nonrig_out,
+                  void *stream);
 
 /* Backward of one level wrt its parameters given g = dL/dx_out [n][3] (autograd of nets.py:111-140;
  * x is a detached input, registration.py:243-249).  act/heads come from ndp_level_fwd on the same
  * x and params; act is CONSUMED (its h2 plane is overwritten with an intermediate).  dO_work is
- * scratch of [n_cap][16] floats.  grads_part [n_part][P_stride] receives n_part partial sums
+ * scratch of [n_cap][16] floats; g_nr (may be NULL) = dL/d(gate) [n] when desc->nonrigidity.  grads_part [n_part][P_stride] receives n_part partial sums
  * (deterministic: workgroup g sums tiles g, g+n_part, ...); ndp_grad_reduce folds them in index order. */
 int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
-                  const float *x, int n, float *act, const float *heads, const float *g, float *dO_work,
-                  float *grads_part, int n_part, int p_stride, void *stream);
+                  const float *x, int n, float *act, const float *heads, const float *g, const float *g_nr,
+                  float *dO_work, float *grads_part, int n_part, int p_stride, void *stream);
 
 /* grads[P] = sum_{g<n_part} grads_part[g][:]  (fixed order). */
 int ndp_grad_reduce(const float *grads_part, int n_part, int p_stride, int P, float *grads, void *stream);
 
 /* Whole pyramid forward, levels 0..m-1 (Deformation_Pyramid.warp, nets.py:36-48; the final
  * inference warp of registration.py:254-255).  params_all: level l at params_all + l*p_stride.
+ * desc->nonrigidity = 1 means "every level but the first carries the gate" (nets.py:26).
  * tmp [n][3] scratch.                                                                           */
 int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const float *params_all, int p_stride,
                     const float *x, int n, float *x_out, float *tmp, void *stream);
@@ -114,7 +118,7 @@ typedef struct ndp_pair_state {
 enum { NDP_DEC_STEP = 0, NDP_DEC_ADVANCE = 1, NDP_DEC_STEP_ADVANCE = 2, NDP_DEC_IDLE = 3 };
 
 typedef struct ndp_engine {
-    ndp_layer_desc desc;             /* shared by all levels (nonrigidity unsupported here)     */
+    ndp_layer_desc desc;             /* shared by all levels; nonrigidity = 1: levels > 0 gated  */
     int m, k0;
     int P, p_stride;                 /* params per level, padded stride (multiple of 4)         */
     int iters, max_break_count, early_stop;
@@ -123,6 +127,7 @@ typedef struct ndp_engine {
     double break_threshold_ratio;
     float w_cd, trunc;
     float adam_w1, adam_b2, adam_w2, adam_eps;
+    float w_reg, pad_f;              /* nonrigidity BCE weight (registration.py:216-220)         */
     const ndp_pair_geom *geom;       /* [B]                                                     */
     ndp_pair_state *state;           /* [2][B] double-buffered by tick parity                   */
     float *pts;                      /* [B][2][n_cap][3]  landmarks first, then samples         */

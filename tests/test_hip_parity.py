@@ -265,3 +265,75 @@ def test_engine_is_deterministic_and_G_independent_in_loss(dev):
     assert torch.equal(e1.params, e2.params)                              # bit-reproducible run to run
     e3, s3, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=8)
     assert abs(s1[0].loss - s3[0].loss) < 1e-5 * abs(s1[0].loss)
+
+
+# ------------------------------------------------------------------- nonrigidity gate + BCE (w_reg > 0)
+@pytest.mark.parametrize("tag", ["se3aa", "sim3quat", "sflow"])
+def test_gate_forward_backward_matches_oracle_and_reference(dev, golden, tag):
+    from deformationpyramid_amd import ops
+    g = golden("F11_nonrigidity")
+    pyr = seeded_pyramid(int(g["seed"]), m=6, nonrigidity_est=True, **VARIANTS[tag])
+    lvl = 4
+    scale_heads(pyr, lvl, float(g["head_scale"]))
+    d = pyr.descs[lvl]
+    assert d.nonrigidity and not pyr.descs[0].nonrigidity
+    p = pyr.store[lvl].to(dev)
+    x = torch.from_numpy(g["x"]).to(dev)
+    out, act, heads, nr = ops.level_fwd(d, p, lvl, K0, x, save=True, want_nonrig=True)
+    tol = 1e-5 if "quat" in tag else 2e-6
+    assert np.abs(out.cpu().numpy() - g[f"{tag}.out"]).max() < tol                  # vs the reference
+    assert np.abs(nr.cpu().numpy() - g[f"{tag}.nonrig"]).max() < 1e-6
+    ro, rn = O().level_fwd(cdesc(d), pyr.store[lvl, :d.param_count].numpy(), lvl, K0, g["x"], want_nonrig=True)
+    assert np.abs(out.cpu().numpy() - ro).max() < tol and np.abs(nr.cpu().numpy() - rn).max() < 1e-6
+    coef = torch.linspace(-1.0, 1.0, 256 * 3).reshape(256, 3).to(dev)
+    c2 = torch.linspace(0.5, -0.25, 256).to(dev)
+    got = ops.level_bwd(d, p, lvl, K0, x, act, heads, coef, g_nr=c2).cpu().numpy()
+    for name, off, shape in d.named_slices():
+        ref = g[f"{tag}.grad.{name}"]
+        e = rel_err(got[off:off + ref.size].reshape(ref.shape), ref)
+        assert e < 2e-4, (tag, name, e)
+    full = ops.pyramid_fwd(d, 6, K0, pyr.store.to(dev), x).cpu().numpy()
+    assert np.abs(full - g[f"{tag}.full_out"]).max() < 1e-4
+
+
+def test_engine_with_bce_regulariser_matches_oracle(dev, golden):
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    from deformationpyramid_amd.layout import LayerDesc
+    g = golden("F11_nonrigidity")
+    m, iters, w_reg = 3, 5, 0.5
+    gated = LayerDesc(nonrigidity=True)
+    cfg = OptConfig(m=m, iters=iters, early_stop=False, w_reg=w_reg)
+    eng = BatchedEngine(gated, cfg, 2, n_cap=300, t_cap=280, device=dev)
+    refs = []
+    for b in range(2):
+        pyr = seeded_pyramid(int(g["it.seed"]) + b, m=m, nonrigidity_est=True, **VARIANTS["se3aa"])
+        x = g["it.x"][: 300 - 11 * b]
+        y = g["it.y"][: 280 - 5 * b]
+        eng.load(b, torch.from_numpy(x), 0, x.shape[0], None, torch.from_numpy(y), pyr.store)
+        descs = [cdesc(dd) for dd in pyr.descs]
+        pa = np.concatenate([pyr.store[i, :dd.param_count].numpy() for i, dd in enumerate(pyr.descs)])
+        refs.append(O().optimize(descs, pa, x, 0, x.shape[0], None, y, iters=iters, early_stop=False, w_reg=w_reg, nthreads=4))
+    states = eng.run_until_done(chunk=8)
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.level == m and st.total_steps == m * iters
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1]), (st.loss, ref["loss_trace"][-1])
+        assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+
+
+def test_register_with_w_reg_runs_end_to_end(dev, golden):
+    import os
+    from deformationpyramid_amd.config import Config, load_config
+    from deformationpyramid_amd.registration import Registration
+    from deformationpyramid_amd.synthetic import synthetic_pair
+    g = golden("F11_nonrigidity")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    c = Config(load_config(os.path.join(root, "config", "NDP.yaml"), device=0), samples=256, w_reg=0.3, m=5)
+    src, tgt, _, _ = synthetic_pair(11, n_total=2048)
+    torch.manual_seed(4)
+    model = Registration(c)
+    model.load_pcds(src.numpy(), tgt.numpy())
+    warped, cnt, _ = model.register()
+    counts = np.array([cnt[l] for l in range(5)])
+    ref = g["e2e.iters_per_level"]
+    assert abs(int(counts[0]) - int(ref[0])) <= 3, (counts, ref)
+    assert np.abs(warped.cpu().numpy() - g["e2e.warped"]).mean() < 0.08               # chaos bar, see test_registration_gpu

@@ -42,13 +42,17 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     from deformationpyramid_amd.layout import LayerDesc
     L = _native.lib()
     bad = LayerDesc(width=64).c_struct()
-    rc = L.ndp_level_fwd(ctypes.byref(bad), None, 0, -8, None, 0, None, None, None, None)
+    rc = L.ndp_level_fwd(ctypes.byref(bad), None, 0, -8, None, 0, None, None, None, None, None)
     assert rc == -2 and b"width=128" in L.ndp_last_error()
     ok = LayerDesc().c_struct()
-    assert L.ndp_level_fwd(ctypes.byref(ok), None, 0, -8, None, 5, None, None, None, None) == -1
+    assert L.ndp_level_fwd(ctypes.byref(ok), None, 0, -8, None, 5, None, None, None, None, None) == -1
     assert L.ndp_chamfer_nn_fwd(None, 0, None, 0, None, None, None, None, None) == -1
-    gate = LayerDesc(nonrigidity=True).c_struct()               # w_reg > 0 is not served by the HIP path yet
-    assert L.ndp_level_fwd(ctypes.byref(gate), None, 0, -8, None, 0, None, None, None, None) == -2
+    deep = LayerDesc(n_hidden=3).c_struct()                     # depth 4: kernels are specialised for depth 3
+    assert L.ndp_level_fwd(ctypes.byref(deep), None, 0, -8, None, 0, None, None, None, None, None) == -2
+    for fmt in ("axis_angle", "euler", "quaternion", "6D"):     # n = 0 is a valid no-op for every served variant
+        for gate in (False, True):
+            d = LayerDesc(rotfmt=fmt, nonrigidity=gate).c_struct()
+            assert L.ndp_level_fwd(ctypes.byref(d), ctypes.c_void_p(16), 0, -8, None, 0, None, None, None, None, None) == 0
 
 
 def test_no_cpu_fallback():
