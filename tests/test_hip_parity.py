@@ -337,3 +337,30 @@ def test_register_with_w_reg_runs_end_to_end(dev, golden):
     ref = g["e2e.iters_per_level"]
     assert abs(int(counts[0]) - int(ref[0])) <= 3, (counts, ref)
     assert np.abs(warped.cpu().numpy() - g["e2e.warped"]).mean() < 0.08               # chaos bar, see test_registration_gpu
+
+
+# ------------------------------------------------------------------- BASELINE.json configs 4 and 5 as parity cases
+def test_config4_shape_transfer_sizes_sim3_euler(dev):
+    """shape_transfer.py: Sim3 / euler, ALL 6000 surface samples per cloud, then a 24 856-vertex inference warp."""
+    from deformationpyramid_amd import ops
+    eng, states, refs = _engine_vs_oracle(dev, "sim3eu", K=0, S=6000, T=6000, m=2, iters=3, early_stop=False,
+                                          w_cd=1.0, trunc=1e9, B=1)
+    st, ref = states[0], refs[0]
+    assert st.total_steps == 6
+    assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+    assert np.abs(eng.final_points(0, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+    verts = cloud(24856, 77)
+    d = eng.desc
+    got = ops.pyramid_fwd(d, 2, K0, eng.params[0], verts.to(dev)).cpu().numpy()
+    want = O().pyramid_fwd([cdesc(d)] * 2, K0, eng.params[0, :, :eng.P].cpu().numpy().reshape(-1), verts.numpy(), nthreads=4)
+    assert np.abs(got - want).max() < 1e-5
+
+
+def test_config5_lndp_sizes(dev):
+    """LNDP.yaml: K = 500 precomputed landmark correspondences, m = 10 levels, no Chamfer (w_cd = 0)."""
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=500, S=0, T=0, m=10, iters=3, early_stop=False,
+                                          w_cd=0.0, trunc=0.25, B=2)
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.level == 10 and st.total_steps == 30
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+        assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4

@@ -170,3 +170,52 @@ def test_native_rng_replay_matches_torch():
         out = torch.zeros(700)
         _native.rng_replay([(skip, 0.0, 1.0, -1), (700, -0.25, 1.75, 0)] if skip else [(700, -0.25, 1.75, 0)], out)
         assert torch.equal(out, x), skip
+
+
+def test_meshio_roundtrip_and_area_weighted_sampling(tmp_path):
+    from deformationpyramid_amd.meshio import read_ply_ascii, sample_surface, write_ply_ascii
+    # a unit square made of one big and one tiny triangle + a quad face (fan-triangulated on read)
+    verts = np.array([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0], [2, 0, 0], [2, 0.01, 0]], dtype=np.float32)
+    faces = np.array([[0, 1, 2], [1, 4, 5]], dtype=np.int64)
+    path = tmp_path / "m.ply"
+    write_ply_ascii(str(path), verts, faces)
+    v, f = read_ply_ascii(str(path))
+    np.testing.assert_array_equal(v, verts)
+    np.testing.assert_array_equal(f, faces)
+    with open(path, "a") as fh:                                  # append a quad: needs the header count bumped
+        pass
+    text = open(path).read().replace("element face 2", "element face 3") + "4 0 1 2 3\n"
+    open(path, "w").write(text)
+    v, f = read_ply_ascii(str(path))
+    assert f.shape == (4, 3) and f[2].tolist() == [0, 1, 2] and f[3].tolist() == [0, 2, 3]
+    pts = sample_surface(verts, faces, 4000, np.random.default_rng(0))
+    assert pts.shape == (4000, 3) and pts.dtype == np.float32
+    big = (pts[:, 0] <= 1.0).mean()                              # area 0.5 vs 0.005: ~99 % of the samples on the big one
+    assert 0.97 < big <= 1.0
+    assert np.all(pts[:, 2] == 0) and pts[:, 1].min() >= 0
+
+
+def test_4dmatch_npz_reader_builds_ground_truth_like_upstream(tmp_path):
+    """eval_nolearned.FourDMatchPairs: npz schema (_4dmatch.py:60-73) and GT flow / overlap (eval_nolearned.py:75-84)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("eval_nolearned", os.path.join(ROOT, "eval_nolearned.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(1)
+    n, m = 50, 40
+    s_pc, t_pc = rng.random((n, 3)).astype(np.float32), rng.random((m, 3)).astype(np.float32)
+    flow = (0.05 * rng.standard_normal((n, 3))).astype(np.float32)
+    ang = 0.3
+    rot = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=np.float32)
+    trn = np.array([[0.1], [0.0], [-0.05]], dtype=np.float32)
+    corr = np.stack([np.arange(0, 30), np.arange(0, 30)], 1)
+    d = tmp_path / "4DMatch-F" / "seq"
+    d.mkdir(parents=True)
+    np.savez(d / "cam1_0000_cam2_0001.npz", s_pc=s_pc, t_pc=t_pc, s2t_flow=flow, rot=rot, trans=trn, correspondences=corr)
+    ds = mod.FourDMatchPairs(str(tmp_path), "4DMatch-F")
+    assert len(ds) == 1
+    src, tgt, flow_gt, overlap = ds[0]
+    want = (rot @ (s_pc + flow).T + trn).T - s_pc
+    np.testing.assert_allclose(flow_gt.numpy(), want, rtol=0, atol=1e-6)
+    assert overlap.sum().item() == 30 and overlap[:30].all() and not overlap[30:].any()
+    assert src.shape == (n, 3) and tgt.shape == (m, 3)
