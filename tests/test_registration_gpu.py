@@ -156,3 +156,50 @@ def test_autograd_wrappers_drive_a_caller_owned_loop(cfg):
     assert all(p.grad is None for p in ndp.pyramid[1].parameters())
     full, _ = ndp.warp(src)
     assert full.shape == src.shape
+
+
+def _uv_sphere(nu, nv, radii, bump=0.0):
+    """Closed triangulated ellipsoid (poles duplicated per meridian -- fine for sampling)."""
+    u = np.linspace(0.0, np.pi, nu)
+    v = np.linspace(0.0, 2 * np.pi, nv, endpoint=False)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    r = 1.0 + bump * np.sin(3 * uu) * np.cos(2 * vv)
+    verts = np.stack([radii[0] * r * np.sin(uu) * np.cos(vv), radii[1] * r * np.sin(uu) * np.sin(vv),
+                      radii[2] * r * np.cos(uu)], -1).reshape(-1, 3).astype(np.float32)
+    faces = []
+    for i in range(nu - 1):
+        for j in range(nv):
+            a, b = i * nv + j, i * nv + (j + 1) % nv
+            c, d = a + nv, b + nv
+            faces += [(a, c, b), (b, c, d)]
+    return verts, np.asarray(faces, dtype=np.int64)
+
+
+def test_shape_transfer_driver_on_generated_meshes(tmp_path):
+    """shape_transfer.py end to end (Sim3 / euler, m=9, 6000 samples): a unit sphere is fitted to a 1.8x bumpy,
+    rotated, shifted ellipsoid; the pyramid must absorb the scale and the warped mesh must land on the target."""
+    import subprocess
+    import sys
+    from deformationpyramid_amd.meshio import read_ply_ascii, write_ply_ascii
+    sv, sf = _uv_sphere(40, 64, (1.0, 1.0, 1.0))
+    tv, tf = _uv_sphere(40, 64, (1.8, 1.5, 2.1), bump=0.08)
+    ang = 0.4
+    rot = np.array([[np.cos(ang), -np.sin(ang), 0], [np.sin(ang), np.cos(ang), 0], [0, 0, 1]], dtype=np.float32)
+    tv = tv @ rot.T + np.array([3.0, -1.0, 0.5], dtype=np.float32)
+    write_ply_ascii(str(tmp_path / "s.ply"), sv, sf)
+    write_ply_ascii(str(tmp_path / "t.ply"), tv, tf)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "shape_transfer.py"), "-s", str(tmp_path / "s.ply"),
+                          "-t", str(tmp_path / "t.ply"), "-o", str(tmp_path / "w.ply")],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    wv, wf = read_ply_ascii(str(tmp_path / "w.ply"))
+    assert wv.shape == sv.shape and np.array_equal(wf, sf)
+    # the warped vertices live in the target's centred frame (upstream does not add tgt_mean back)
+    tc = torch.from_numpy(tv - tv.mean(0, keepdims=True)).cuda()
+    w = torch.from_numpy(wv).cuda()
+    d = torch.cdist(w, tc)
+    cd = d.min(1).values.mean().item() + d.min(0).values.mean().item()
+    d0 = torch.cdist(torch.from_numpy(sv).cuda(), tc)
+    cd0 = d0.min(1).values.mean().item() + d0.min(0).values.mean().item()
+    assert cd0 > 1.0 and cd < 0.15 * cd0, (cd0, cd, out.stdout[-500:])
