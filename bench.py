@@ -50,7 +50,7 @@ def kernel_profile(model, pairs, slots, n_ticks=24):
     preps = [model._prepare(s, t, None) for s, t in pairs[:slots]]
     eng = model._engine(len(preps), preps[0])
     for b, p in enumerate(preps):
-        eng.load(b, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.store)
+        eng.load_jobs([p.load_job(b)])
     eng.run_ticks(4)                                  # warm-up ticks
     ms = eng.run_ticks_timed(n_ticks)
     st = eng.read_states()
@@ -217,7 +217,7 @@ def main():
 
     if rank == 0 and n_gpus == 1 and not args.no_roofline:
         prof, eng, preps, active = kernel_profile(model, pairs, B)
-        S, T = preps[0].S, preps[0].tgt_sample.shape[0]
+        S, T = preps[0].S, preps[0].T
         P = eng.P
         dom = max(prof, key=prof.get)
         # backward split by layer: bwdh = heads (2*768 MAC), bwd2 = dW2 + dh1, bwd1 = dW1 + dh0 + dW0 (768 MAC)

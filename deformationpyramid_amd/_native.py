@@ -60,6 +60,22 @@ class Engine(ctypes.Structure):
                 ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p), ("dO", ctypes.c_void_p)]
 
 
+class WarpJob(ctypes.Structure):
+    _fields_ = [("params", ctypes.c_void_p), ("x", ctypes.c_void_p), ("x_out", ctypes.c_void_p),
+                ("shift_in", ctypes.c_void_p), ("shift_out", ctypes.c_void_p), ("n", ctypes.c_int), ("pad", ctypes.c_int)]
+
+
+class LoadJob(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("tgt", ctypes.c_void_p), ("perm_s", ctypes.c_void_p),
+                ("perm_t", ctypes.c_void_p), ("ldmk_s", ctypes.c_void_p), ("ldmk_t", ctypes.c_void_p),
+                ("params", ctypes.c_void_p), ("means", ctypes.c_void_p),
+                ("slot", ctypes.c_int), ("K", ctypes.c_int), ("S", ctypes.c_int), ("T", ctypes.c_int)]
+
+
+MAX_WARP_JOBS = 32
+MAX_LOAD_JOBS = 16
+
+
 def _stale():
     if not os.path.exists(LIBPATH):
         return True
@@ -96,12 +112,15 @@ _SIGS = {
     "ndp_level_bwd": [DP, V, I, I, V, I, V, V, V, V, V, V, I, I, V],
     "ndp_grad_reduce": [V, I, I, I, V, V],
     "ndp_pyramid_fwd": [DP, I, I, V, I, V, I, V, V, V],
+    "ndp_pyramid_fwd_batch": [DP, I, I, I, ctypes.POINTER(WarpJob), I, V],
+    "ndp_pair_means": [V, I, V, I, V, V],
     "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],
     "ndp_chamfer_l1_bwd": [V, I, V, I, F, V, V, V, V, V, V, V],
     "ndp_landmark_mse_fwd_bwd": [V, V, I, V, V, V],
     "ndp_adam_step": [V, V, V, V, I, F, F, F, F, F, F, V],
     "ndp_engine_run": [ctypes.POINTER(Engine), I, I, V],
     "ndp_engine_run_timed": [ctypes.POINTER(Engine), I, I, V, c_float_p],
+    "ndp_engine_load": [ctypes.POINTER(Engine), I, ctypes.POINTER(LoadJob), I, V],
 }
 EXPORTS = ["ndp_version", "ndp_last_error"] + list(_SIGS)
 

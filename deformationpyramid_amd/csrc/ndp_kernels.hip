@@ -133,141 +133,205 @@ __device__ __forceinline__ int mfma_row(int r, int h) { return (r & 3) + 8 * (r 
 // ------------------------------------------------------------------------------------------------
 // Level forward  (nets.py:111-140)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob &job, float *sm) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
-    float *bufA = sm + L_BUFA, *bufB = sm + L_BUFB, *pe = sm + L_PE, *xs = sm + L_XS;
-    float *whs = sm + L_WH, *bhs = sm + L_BH, *ho = sm + L_HO;
+// lane-resident operands of one level (weight-stationary for as long as the level lasts)
+struct FwdWeights {
+    float w1[64], w2[64], w0b[3];
+    float bias0, bias1, bias2;
+};
 
+// Loads a level's weights into registers and stages its head matrix in LDS.  The caller must pass a barrier
+// before the first tile's head phase (the tile's own barriers do) and after the last one before reloading.
+__device__ __forceinline__ void fwd_load_weights(const HeadCfg &hc, const float *P, float *sm, FwdWeights &fw) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *whs = sm + L_WH, *bhs = sm + L_BH;
     const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
-    const float *P = job.params;
     const float *W0 = P + ndp_off_W0(&dd), *b0 = P + ndp_off_b0(&dd);
     const float *W1 = P + ndp_off_Wi(&dd, 1), *b1 = P + ndp_off_bi(&dd, 1);
     const float *W2 = P + ndp_off_Wi(&dd, 2), *b2 = P + ndp_off_bi(&dd, 2);
     const float *Wh = P + ndp_off_Wi(&dd, 3);      // == ndp_off_Wh for nonrigidity = 0
     const float *bh = Wh + hc.nh * NDP_W;
-
-    // weight-stationary operands
-    float w1[64], w2[64];
-    load_w_fwd(W1, wv, l31, h, w1);
-    load_w_fwd(W2, wv, l31, h, w2);
-    const float bias1 = b1[32 * wv + l31], bias2 = b2[32 * wv + l31];
+    load_w_fwd(W1, wv, l31, h, fw.w1);
+    load_w_fwd(W2, wv, l31, h, fw.w2);
+    fw.bias1 = b1[32 * wv + l31];
+    fw.bias2 = b2[32 * wv + l31];
     // layer 0 (6 -> 128) also runs on the matrix pipe: K = 6 = 3 k-steps of the 32x32x2 MFMA
-    float w0b[3];
 #pragma unroll
-    for (int ks = 0; ks < 3; ++ks) w0b[ks] = W0[(32 * wv + l31) * 6 + 2 * ks + h];
-    const float bias0 = b0[32 * wv + l31];
+    for (int ks = 0; ks < 3; ++ks) fw.w0b[ks] = W0[(32 * wv + l31) * 6 + 2 * ks + h];
+    fw.bias0 = b0[32 * wv + l31];
     for (int i = t; i < 12 * NDP_W; i += 256) whs[i] = (i < hc.nh * NDP_W) ? Wh[i] : 0.f;
     if (t < NDP_NHMAX) bhs[t] = (t < hc.nh) ? bh[t] : 0.f;
+}
 
-    for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
-        const int base = tile * NDP_TILE;
-        // ---- positional encoding (nets.py:164-177): thread (point = lane, axis = wave) for waves 0..2
-        if (wv < 3) {
-            const int p = base + lane;
-            const float xa = p < job.n ? job.x_in[3 * p + wv] : 0.f;
-            const float phs = xa * job.freq;
-            float sn, cs;
-            sincosf(phs, &sn, &cs);
-            pe[lane * 9 + 2 * wv] = sn;
-            pe[lane * 9 + 2 * wv + 1] = cs;
+// where one tile's input comes from and where its outputs go
+struct TileIO {
+    const float *x_in;      // global [n][3], or nullptr: the tile's input already sits in LDS (xs)
+    const float *shift_in;  // [3] subtracted from x_in (or nullptr)
+    float *x_out;           // global [n][3], or nullptr: the warped points replace xs (next level reads them)
+    const float *shift_out; // [3] added to x_out (or nullptr)
+    float *act;             // [3][plane][128] or nullptr
+    float *heads;           // [plane][NDP_HROW] or nullptr
+    float *nonrig;          // [n] or nullptr
+    int n, plane;
+};
+
+// One 64-point tile through one level: posenc -> 3 layers on MFMA -> heads -> warp.  Ends with a barrier.
+__device__ __forceinline__ void fwd_tile(const HeadCfg &hc, const FwdWeights &fw, float freq, const TileIO &io,
+                                         int base, float *sm) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *bufA = sm + L_BUFA, *bufB = sm + L_BUFB, *pe = sm + L_PE, *xs = sm + L_XS;
+    float *whs = sm + L_WH, *bhs = sm + L_BH, *ho = sm + L_HO;
+    // ---- positional encoding (nets.py:164-177): thread (point = lane, axis = wave) for waves 0..2
+    if (wv < 3) {
+        const int p = base + lane;
+        float xa;
+        if (io.x_in) {
+            xa = p < io.n ? io.x_in[3 * p + wv] : 0.f;
+            if (io.shift_in) xa = p < io.n ? xa - io.shift_in[wv] : 0.f;
             xs[4 * lane + wv] = xa;
+        } else {
+            xa = xs[4 * lane + wv];
         }
-        __syncthreads();
-        // ---- layer 0 (MFMA, bitwise the k = 0..5 fmaf chain starting from the bias) -> bufA
-        {
-            f32x16 acc0, acc1;
+        const float phs = xa * freq;
+        float sn, cs;
+        sincosf(phs, &sn, &cs);
+        pe[lane * 9 + 2 * wv] = sn;
+        pe[lane * 9 + 2 * wv + 1] = cs;
+    }
+    __syncthreads();
+    // ---- layer 0 (MFMA, bitwise the k = 0..5 fmaf chain starting from the bias) -> bufA
+    {
+        f32x16 acc0, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = bias0; acc1[r] = bias0; }
+        for (int r = 0; r < 16; ++r) { acc0[r] = fw.bias0; acc1[r] = fw.bias0; }
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                const float a0 = pe[l31 * 9 + 2 * ks + h], a1 = pe[(l31 + 32) * 9 + 2 * ks + h];
-                acc0 = MFMA32(a0, w0b[ks], acc0);
-                acc1 = MFMA32(a1, w0b[ks], acc1);
-            }
-            const int col = 32 * wv + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, h);
-                bufA[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
-                bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
-            }
+        for (int ks = 0; ks < 3; ++ks) {
+            const float a0 = pe[l31 * 9 + 2 * ks + h], a1 = pe[(l31 + 32) * 9 + 2 * ks + h];
+            acc0 = MFMA32(a0, fw.w0b[ks], acc0);
+            acc1 = MFMA32(a1, fw.w0b[ks], acc1);
         }
-        __syncthreads();
-        // ---- layer 1 (MFMA) bufA -> bufB ; h0 goes to HBM as float4 rows while the matrix pipe works
-        {
-            f32x16 acc0, acc1;
+        const int col = 32 * wv + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = bias1; acc1[r] = bias1; }
-            if (job.act) store_tile_from_lds(bufA, job.act + (size_t)base * NDP_W);
-            tile_gemm_64x32(bufA, w1, l31, h, acc0, acc1);
-            const int col = 32 * wv + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, h);
-                bufB[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
-                bufB[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, h);
+            bufA[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
+            bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
         }
-        __syncthreads();
-        // ---- layer 2 (MFMA) bufB -> bufA ; h1 -> HBM
-        {
-            f32x16 acc0, acc1;
+    }
+    __syncthreads();
+    // ---- layer 1 (MFMA) bufA -> bufB ; h0 goes to HBM as float4 rows while the matrix pipe works
+    {
+        f32x16 acc0, acc1;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc0[r] = bias2; acc1[r] = bias2; }
-            if (job.act) store_tile_from_lds(bufB, job.act + ((size_t)job.plane + base) * NDP_W);
-            tile_gemm_64x32(bufB, w2, l31, h, acc0, acc1);
-            const int col = 32 * wv + l31;
+        for (int r = 0; r < 16; ++r) { acc0[r] = fw.bias1; acc1[r] = fw.bias1; }
+        if (io.act) store_tile_from_lds(bufA, io.act + (size_t)base * NDP_W);
+        tile_gemm_64x32(bufA, fw.w1, l31, h, acc0, acc1);
+        const int col = 32 * wv + l31;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, h);
-                bufA[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
-                bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, h);
+            bufB[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
+            bufB[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
         }
-        __syncthreads();
-        if (job.act) store_tile_from_lds(bufA, job.act + (2 * (size_t)job.plane + base) * NDP_W);   // h2 -> HBM
-        // ---- heads (nets.py:117,125,146): thread (p = lane, jq = wave) computes heads jq, jq+4, ...
-        {
-            const float *hrow = bufA + lane * NDP_LD;
-            for (int j = wv; j < hc.nh; j += 4) {
-                const float *wr = whs + j * NDP_W;
-                // four independent fmaf chains (k mod 4): a lone 128-long chain is pure FMA latency
-                float a0 = bhs[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    }
+    __syncthreads();
+    // ---- layer 2 (MFMA) bufB -> bufA ; h1 -> HBM
+    {
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = fw.bias2; acc1[r] = fw.bias2; }
+        if (io.act) store_tile_from_lds(bufB, io.act + ((size_t)io.plane + base) * NDP_W);
+        tile_gemm_64x32(bufB, fw.w2, l31, h, acc0, acc1);
+        const int col = 32 * wv + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, h);
+            bufA[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
+            bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
+        }
+    }
+    __syncthreads();
+    if (io.act) store_tile_from_lds(bufA, io.act + (2 * (size_t)io.plane + base) * NDP_W);   // h2 -> HBM
+    // ---- heads (nets.py:117,125,146): thread (p = lane, jq = wave) computes heads jq, jq+4, ...
+    {
+        const float *hrow = bufA + lane * NDP_LD;
+        for (int j = wv; j < hc.nh; j += 4) {
+            const float *wr = whs + j * NDP_W;
+            // four independent fmaf chains (k mod 4): a lone 128-long chain is pure FMA latency
+            float a0 = bhs[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll 8
-                for (int k4 = 0; k4 < 32; ++k4) {
-                    const float4 hv = *reinterpret_cast<const float4 *>(hrow + 4 * k4);
-                    const float4 wv4 = *reinterpret_cast<const float4 *>(wr + 4 * k4);
-                    a0 = fmaf(wv4.x, hv.x, a0);
-                    a1 = fmaf(wv4.y, hv.y, a1);
-                    a2 = fmaf(wv4.z, hv.z, a2);
-                    a3 = fmaf(wv4.w, hv.w, a3);
-                }
-                ho[lane * NDP_NHMAX + j] = hc.mlp_scale * ((a0 + a1) + (a2 + a3));
+            for (int k4 = 0; k4 < 32; ++k4) {
+                const float4 hv = *reinterpret_cast<const float4 *>(hrow + 4 * k4);
+                const float4 wv4 = *reinterpret_cast<const float4 *>(wr + 4 * k4);
+                a0 = fmaf(wv4.x, hv.x, a0);
+                a1 = fmaf(wv4.y, hv.y, a1);
+                a2 = fmaf(wv4.z, hv.z, a2);
+                a3 = fmaf(wv4.w, hv.w, a3);
             }
+            ho[lane * NDP_NHMAX + j] = hc.mlp_scale * ((a0 + a1) + (a2 + a3));
         }
-        __syncthreads();
-        // ---- warp (nets.py:119-129)
-        if (t < 64) {
-            const int p = base + t;
-            const float *o = ho + t * NDP_NHMAX;
-            if (job.heads) {
-                float *hr = job.heads + (size_t)p * NDP_HROW;
+    }
+    __syncthreads();
+    // ---- warp (nets.py:119-129)
+    if (t < 64) {
+        const int p = base + t;
+        const float *o = ho + t * NDP_NHMAX;
+        if (io.heads) {
+            float *hr = io.heads + (size_t)p * NDP_HROW;
 #pragma unroll
-                for (int j = 0; j < NDP_NHMAX; j += 4)
-                    *reinterpret_cast<float4 *>(hr + j) = *reinterpret_cast<const float4 *>(o + j);
-                const float *pr = pe + t * 9;
-                *reinterpret_cast<float4 *>(hr + 16) = make_float4(pr[0], pr[1], pr[2], pr[3]);
-                *reinterpret_cast<float4 *>(hr + 20) = make_float4(pr[4], pr[5], 0.f, 0.f);
-            }
-            if (p < job.n) {
-                PointHead c;
-                float out[3];
-                head_warp_fwd(hc, o, xs + 4 * t, c, out);
-                job.x_out[3 * p] = out[0]; job.x_out[3 * p + 1] = out[1]; job.x_out[3 * p + 2] = out[2];
-                if (job.nonrig) job.nonrig[p] = c.nr;
-            }
+            for (int j = 0; j < NDP_NHMAX; j += 4)
+                *reinterpret_cast<float4 *>(hr + j) = *reinterpret_cast<const float4 *>(o + j);
+            const float *pr = pe + t * 9;
+            *reinterpret_cast<float4 *>(hr + 16) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+            *reinterpret_cast<float4 *>(hr + 20) = make_float4(pr[4], pr[5], 0.f, 0.f);
         }
-        __syncthreads();
+        if (p < io.n) {
+            PointHead c;
+            float out[3];
+            head_warp_fwd(hc, o, xs + 4 * t, c, out);
+            if (io.x_out) {
+                if (io.shift_out) { out[0] += io.shift_out[0]; out[1] += io.shift_out[1]; out[2] += io.shift_out[2]; }
+                io.x_out[3 * p] = out[0]; io.x_out[3 * p + 1] = out[1]; io.x_out[3 * p + 2] = out[2];
+            } else {
+                xs[4 * t] = out[0]; xs[4 * t + 1] = out[1]; xs[4 * t + 2] = out[2];
+            }
+            if (io.nonrig) io.nonrig[p] = c.nr;
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob &job, float *sm) {
+    FwdWeights fw;
+    fwd_load_weights(hc, job.params, sm, fw);
+    TileIO io;
+    io.x_in = job.x_in; io.shift_in = nullptr; io.x_out = job.x_out; io.shift_out = nullptr;
+    io.act = job.act; io.heads = job.heads; io.nonrig = job.nonrig; io.n = job.n; io.plane = job.plane;
+    for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step)
+        fwd_tile(hc, fw, job.freq, io, tile * NDP_TILE, sm);
+}
+
+// Whole pyramid for one 64-point tile per workgroup: the points stay in LDS from level to level, the weights of
+// each level are re-read from L2 (135 KB per level; the grid is sized so that several clouds fill the chip).
+struct WarpJobs {
+    ndp_warp_job j[NDP_MAX_WARP_JOBS];
+};
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_pyramid_fwd(ndp_layer_desc desc, int m, int k0, int p_stride, WarpJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const ndp_warp_job jb = jobs.j[blockIdx.y];
+    const int base = blockIdx.x * NDP_TILE;
+    if (base >= jb.n) return;
+    TileIO io;
+    io.act = nullptr; io.heads = nullptr; io.nonrig = nullptr; io.n = jb.n; io.plane = 0;
+    for (int l = 0; l < m; ++l) {
+        const HeadCfg hc = make_head_cfg(desc_at_level(desc, l));
+        FwdWeights fw;
+        fwd_load_weights(hc, jb.params + (size_t)l * p_stride, sm, fw);
+        io.x_in = l == 0 ? jb.x : nullptr;
+        io.shift_in = l == 0 ? jb.shift_in : nullptr;
+        io.x_out = l == m - 1 ? jb.x_out : nullptr;
+        io.shift_out = l == m - 1 ? jb.shift_out : nullptr;
+        fwd_tile(hc, fw, ldexpf(1.0f, l + 1 + k0), io, base, sm);
     }
 }
 
@@ -1125,6 +1189,103 @@ k_eng_update(ndp_engine e, int parity) {
     if (ns.decision != NDP_DEC_STEP) { m[i] = 0.f; v[i] = 0.f; }             // registration.py:176
 }
 
+// ---- pair preparation (registration.py:150-164) and slot (re)fill, batched over pairs ----------------------
+// means of two clouds: blockIdx.x = 0 source, 1 target.  Double accumulation in a fixed order, one rounding.
+extern "C" __global__ void __launch_bounds__(1024)
+k_pair_means(const float *src, int n_src, const float *tgt, int n_tgt, float *means) {
+    __shared__ double red[3][1024];
+    const float *x = blockIdx.x ? tgt : src;
+    const int n = blockIdx.x ? n_tgt : n_src, t = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int p0 = t; p0 < n; p0 += 4 * 1024) {               // four independent loads in flight per thread
+        float v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + 1024 * u;
+            v[u][0] = v[u][1] = v[u][2] = 0.f;
+            if (p < n) { v[u][0] = x[3 * (size_t)p]; v[u][1] = x[3 * (size_t)p + 1]; v[u][2] = x[3 * (size_t)p + 2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 += (double)v[u][0]; s1 += (double)v[u][1]; s2 += (double)v[u][2]; }
+    }
+    red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1) {
+        if (t < d) { red[0][t] += red[0][t + d]; red[1][t] += red[1][t + d]; red[2][t] += red[2][t + d]; }
+        __syncthreads();
+    }
+    if (t < 4) means[4 * blockIdx.x + t] = t < 3 ? (float)(red[t][0] / (double)n) : 0.f;
+}
+
+struct LoadJobs {
+    ndp_load_job j[NDP_MAX_LOAD_JOBS];
+};
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_load(ndp_engine e, int parity, LoadJobs jobs) {
+    const ndp_load_job jb = jobs.j[blockIdx.y];
+    const int b = jb.slot, t = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+    ndp_pair_state *st = e.state + (size_t)parity * e.B + b;
+    if (!jb.params) {                                        // park: the slot reads as finished
+        if (t == 0) {
+            ndp_pair_state c;
+            memset(&c, 0, sizeof c);
+            c.level = e.m;
+            c.decision = NDP_DEC_IDLE;
+            *st = c;
+        }
+        return;
+    }
+    float ms[3] = {0.f, 0.f, 0.f}, mt[3] = {0.f, 0.f, 0.f};
+    if (jb.means) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { ms[a] = jb.means[a]; mt[a] = jb.means[4 + a]; }
+    }
+    const int n = jb.K + jb.S;
+    // centred landmarks + centred source samples -> point buffer 0 (rest of the plane zero)
+    float *pts = e.pts + (size_t)b * 2 * e.n_cap * 3;
+    for (int i = t; i < e.n_cap; i += stride) {
+        float v[3] = {0.f, 0.f, 0.f};
+        if (i < n) {
+            const float *q = i < jb.K ? jb.ldmk_s + 3 * (size_t)i
+                                      : jb.src + 3 * (size_t)(jb.perm_s ? jb.perm_s[i - jb.K] : i - jb.K);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = q[a] - ms[a];
+        }
+        pts[3 * i] = v[0]; pts[3 * i + 1] = v[1]; pts[3 * i + 2] = v[2];
+    }
+    float *lt = e.ldmk_t + (size_t)b * e.n_cap * 3;
+    for (int i = t; i < jb.K; i += stride) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) lt[3 * i + a] = jb.ldmk_t[3 * (size_t)i + a] - mt[a];
+    }
+    float *tg = e.tgt + (size_t)b * e.t_cap * 3;
+    for (int i = t; i < jb.T; i += stride) {
+        const float *q = jb.tgt + 3 * (size_t)(jb.perm_t ? jb.perm_t[i] : i);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tg[3 * i + a] = q[a] - mt[a];
+    }
+    // parameters of every level, fresh Adam moments
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(jb.params);
+        float4 *dst = reinterpret_cast<float4 *>(e.params + (size_t)b * e.m * e.p_stride);
+        const int n4 = e.m * e.p_stride / 4;
+        for (int i = t; i < n4; i += stride) dst[i] = src[i];
+        float4 *am = reinterpret_cast<float4 *>(e.adam_m + (size_t)b * e.p_stride);
+        float4 *av = reinterpret_cast<float4 *>(e.adam_v + (size_t)b * e.p_stride);
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = t; i < e.p_stride / 4; i += stride) { am[i] = z; av[i] = z; }
+    }
+    if (t == 0) {
+        ndp_pair_geom g;
+        g.K = jb.K; g.S = jb.S; g.T = jb.T; g.pad = 0;
+        e.geom[b] = g;
+        ndp_pair_state c;
+        memset(&c, 0, sizeof c);
+        c.loss_prev = 1e6;                                   // registration.py:179
+        *st = c;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ------------------------------------------------------------------------------------------------
@@ -1162,7 +1323,7 @@ static int set_smem(const void *fn, int bytes) {
     return 0;
 }
 
-extern "C" int ndp_version(void) { return 100; }
+extern "C" int ndp_version(void) { return 101; }
 extern "C" const char *ndp_last_error(void) { return g_err; }
 
 extern "C" int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
@@ -1229,23 +1390,96 @@ extern "C" int ndp_grad_reduce(const float *grads_part, int n_part, int p_stride
     return 0;
 }
 
+extern "C" int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_stride,
+                                     const ndp_warp_job *jobs, int n_jobs, void *stream);
+
 extern "C" int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const float *params_all, int p_stride,
                                const float *x, int n, float *x_out, float *tmp, void *stream) {
     if (int rc = check_desc(desc)) return rc;
-    if (m < 0 || m > NDP_MAX_LEVELS || n < 0 || !x_out || (m > 1 && !tmp)) return fail(NDP_E_INVALID, "ndp_pyramid_fwd: bad arguments");
+    if (m < 0 || m > NDP_MAX_LEVELS || n < 0 || !x_out || (n > 0 && !x)) return fail(NDP_E_INVALID, "ndp_pyramid_fwd: bad arguments");
     if (n == 0) return 0;
     if (m == 0) {
         HIP_TRY(hipMemcpyAsync(x_out, x, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream), "memcpy");
         return 0;
     }
-    // ping-pong so that the last level lands in x_out
-    const float *src = x;
-    for (int l = 0; l < m; ++l) {
-        float *dst = ((m - 1 - l) % 2 == 0) ? x_out : tmp;
-        const ndp_layer_desc dl = desc_at_level(*desc, l);       // desc->nonrigidity = "levels > 0 carry the gate"
-        if (int rc = ndp_level_fwd(&dl, params_all + (size_t)l * p_stride, l, k0, src, n, dst, nullptr, nullptr, nullptr, stream)) return rc;
-        src = dst;
+    (void)tmp;                       // kept in the signature for ABI stability; the fused kernel needs no scratch
+    ndp_warp_job job;
+    memset(&job, 0, sizeof job);
+    job.params = params_all; job.x = x; job.x_out = x_out; job.n = n;
+    return ndp_pyramid_fwd_batch(desc, m, k0, p_stride, &job, 1, stream);
+}
+
+extern "C" int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_stride,
+                                     const ndp_warp_job *jobs, int n_jobs, void *stream) {
+    if (int rc = check_desc(desc)) return rc;
+    if (m < 1 || m > NDP_MAX_LEVELS || n_jobs < 0 || (n_jobs > 0 && !jobs) || p_stride < ndp_param_count(desc) || (p_stride & 3))
+        return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch: bad arguments");
+    if (int rc = set_smem((const void *)k_pyramid_fwd, kSmemFwdBytes)) return rc;
+    for (int j0 = 0; j0 < n_jobs; j0 += NDP_MAX_WARP_JOBS) {
+        WarpJobs wj;
+        memset(&wj, 0, sizeof wj);
+        int cnt = 0, max_tiles = 0;
+        for (int j = j0; j < n_jobs && cnt < NDP_MAX_WARP_JOBS; ++j) {
+            const ndp_warp_job &q = jobs[j];
+            if (q.n < 0 || (q.n > 0 && (!q.params || !q.x || !q.x_out))) return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch: null pointer / negative n");
+            if (!aligned16(q.params)) return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch: params must be 16-byte aligned");
+            if (q.n == 0) continue;
+            wj.j[cnt++] = q;
+            const int tiles = (q.n + NDP_TILE - 1) / NDP_TILE;
+            if (tiles > max_tiles) max_tiles = tiles;
+        }
+        if (!cnt) continue;
+        hipLaunchKernelGGL(k_pyramid_fwd, dim3(max_tiles, cnt), dim3(256), kSmemFwdBytes, (hipStream_t)stream,
+                           *desc, m, k0, p_stride, wj);
+        HIP_TRY(hipGetLastError(), "k_pyramid_fwd launch");
     }
+    return 0;
+}
+
+extern "C" int ndp_pair_means(const float *src, int n_src, const float *tgt, int n_tgt, float *means, void *stream) {
+    if (!src || !tgt || !means || n_src < 1 || n_tgt < 1) return fail(NDP_E_INVALID, "ndp_pair_means: bad arguments");
+    hipLaunchKernelGGL(k_pair_means, dim3(2), dim3(1024), 0, (hipStream_t)stream, src, n_src, tgt, n_tgt, means);
+    HIP_TRY(hipGetLastError(), "k_pair_means launch");
+    return 0;
+}
+
+static int check_engine(const ndp_engine *e, const char *who) {
+    if (!e) return fail(NDP_E_INVALID, "null engine");
+    if (int rc = check_desc(&e->desc)) return rc;
+    if (e->B < 1 || e->G < 1 || e->m < 1 || e->m > NDP_MAX_LEVELS || e->n_cap % NDP_TILE || e->t_cap % NDP_TILE ||
+        e->P != ndp_param_count(&e->desc) || e->p_stride < e->P || (e->p_stride & 3)) {
+        snprintf(g_err, sizeof g_err, "%s: inconsistent engine descriptor", who);
+        return NDP_E_INVALID;
+    }
+    if (!e->geom || !e->state || !e->pts || !e->params || !e->gpart || !e->adam_m || !e->adam_v || !e->act ||
+        !e->heads || !e->adam_tab || !e->dO) {
+        snprintf(g_err, sizeof g_err, "%s: null buffer", who);
+        return NDP_E_INVALID;
+    }
+    return 0;
+}
+
+extern "C" int ndp_engine_load(const ndp_engine *e, int tick, const ndp_load_job *jobs, int n_jobs, void *stream) {
+    if (int rc = check_engine(e, "ndp_engine_load")) return rc;
+    if (n_jobs < 0 || n_jobs > NDP_MAX_LOAD_JOBS || (n_jobs > 0 && !jobs)) return fail(NDP_E_INVALID, "ndp_engine_load: bad job count");
+    if (n_jobs == 0) return 0;
+    LoadJobs lj;
+    memset(&lj, 0, sizeof lj);
+    for (int j = 0; j < n_jobs; ++j) {
+        const ndp_load_job &q = jobs[j];
+        if (q.slot < 0 || q.slot >= e->B) return fail(NDP_E_INVALID, "ndp_engine_load: slot out of range");
+        if (q.params) {
+            if (q.K < 0 || q.S < 0 || q.T < 0 || q.K + q.S < 1 || q.K + q.S > e->n_cap || q.T > e->t_cap)
+                return fail(NDP_E_INVALID, "ndp_engine_load: pair does not fit the engine capacities");
+            if ((q.K > 0 && (!q.ldmk_s || !q.ldmk_t)) || (q.S > 0 && !q.src) || (q.T > 0 && (!q.tgt || !e->tgt)) ||
+                (q.K > 0 && !e->ldmk_t))
+                return fail(NDP_E_INVALID, "ndp_engine_load: null cloud pointer");
+            if (!aligned16(q.params)) return fail(NDP_E_INVALID, "ndp_engine_load: params must be 16-byte aligned");
+        }
+        lj.j[j] = q;
+    }
+    hipLaunchKernelGGL(k_eng_load, dim3(32, n_jobs), dim3(256), 0, (hipStream_t)stream, *e, tick & 1, lj);
+    HIP_TRY(hipGetLastError(), "k_eng_load launch");
     return 0;
 }
 

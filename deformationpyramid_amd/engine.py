@@ -95,45 +95,59 @@ class BatchedEngine:
         self.c_engine = e
 
     # ------------------------------------------------------------------ slot management
-    # Nothing here may block the host: every copy is device->device or pinned->device (a pageable H2D copy is
-    # synchronous and would drain the tick pipeline behind it -- it used to cost 0.25-0.45 ms per call).
-    def _templates(self):
-        if not hasattr(self, "_st_fresh"):
-            st = N.PairState()
-            st.loss_prev = 1e6
-            self._st_fresh = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
-            st = N.PairState()
-            st.level = self.cfg.m
-            self._st_parked = torch.frombuffer(bytearray(bytes(st)), dtype=torch.uint8).to(self.device)
-            self._geom_pin = torch.zeros(self.B, 4, dtype=torch.int32).pin_memory()
-        return self._st_fresh, self._st_parked
+    # Nothing here may block the host: a slot is filled by ONE kernel launch (k_eng_load) from device-resident
+    # inputs (a pageable H2D copy is synchronous and would drain the tick pipeline behind it).
+    def load_jobs(self, jobs):
+        """Fill / park slots, one launch per 16 jobs (ndp_engine_load).  Each job is a dict with `slot` and either
+        nothing else (park) or: params [m,p_stride] device tensor, K, S, T, src [*,3], tgt [*,3] | None,
+        perm_s / perm_t (device int32, first S / T entries used) | None, ldmk_s / ldmk_t [K,3] | None,
+        means [8] | None.  The tensors must stay alive until the launch has run (the caller holds them)."""
+        ptr = lambda t: t.data_ptr() if t is not None else None
+        for i0 in range(0, len(jobs), N.MAX_LOAD_JOBS):
+            group = jobs[i0:i0 + N.MAX_LOAD_JOBS]
+            arr = (N.LoadJob * len(group))()
+            for q, j in zip(arr, group):
+                q.slot = j["slot"]
+                params = j.get("params")
+                if params is None:
+                    continue
+                if params.dtype != torch.float32 or not params.is_cuda or not params.is_contiguous() or \
+                        tuple(params.shape) != (self.cfg.m, self.p_stride):
+                    raise N.NdpError("load_jobs: params must be a contiguous float32 device tensor [m, p_stride]")
+                K, S, T = int(j["K"]), int(j["S"]), int(j.get("T", 0))
+                if K + S > self.n_cap or T > self.t_cap or K + S < 1:
+                    raise ValueError(f"pair does not fit the engine capacities: n={K + S}/{self.n_cap}, T={T}/{self.t_cap}")
+                q.params, q.K, q.S, q.T = params.data_ptr(), K, S, T
+                q.src, q.tgt = ptr(j.get("src")), ptr(j.get("tgt"))
+                q.perm_s, q.perm_t = ptr(j.get("perm_s")), ptr(j.get("perm_t"))
+                q.ldmk_s, q.ldmk_t = ptr(j.get("ldmk_s")), ptr(j.get("ldmk_t"))
+                q.means = ptr(j.get("means"))
+                self._geom_h[q.slot] = (K, S, T, 0)
+            N.check(self.lib.ndp_engine_load(ctypes.byref(self.c_engine), self.tick, arr, len(group),
+                                             N.stream_ptr(self.device)), "ndp_engine_load")
 
     def load(self, slot, pts, K, S, ldmk_t, tgt, params):
-        """pts [K+S,3] centred source points (landmarks first); ldmk_t [K,3]; tgt [T,3];
-        params [m, >=P] initial parameters of every level (device tensor, or pinned/pageable host tensor)."""
-        n = K + S
-        T = 0 if tgt is None else tgt.shape[0]
-        if n > self.n_cap or T > self.t_cap or n < 1:
-            raise ValueError(f"pair does not fit the engine capacities: n={n}/{self.n_cap}, T={T}/{self.t_cap}")
-        fresh, _ = self._templates()
-        self.pts[slot].zero_()
-        self.pts[slot, 0, :n].copy_(pts, non_blocking=True)
-        if K:
-            self.ldmk_t[slot, :K].copy_(ldmk_t, non_blocking=True)
-        if T:
-            self.tgt[slot, :T].copy_(tgt, non_blocking=True)
-        self.params[slot, :, :self.P].copy_(params[:, :self.P], non_blocking=True)
-        self.adam_m[slot].zero_()
-        self.adam_v[slot].zero_()
-        self._geom_h[slot] = (K, S, T, 0)
-        self._geom_pin[slot] = torch.tensor([K, S, T, 0], dtype=torch.int32)
-        self.geom[slot].copy_(self._geom_pin[slot], non_blocking=True)
-        self.state[self.tick & 1, slot].copy_(fresh, non_blocking=True)
+        """Already centred / sampled inputs: pts [K+S,3] (landmarks first); ldmk_t [K,3]; tgt [T,3];
+        params [m, >=P] initial parameters of every level (device or host tensor)."""
+        if pts.shape[0] != K + S:
+            raise ValueError("pts must hold K landmarks followed by S samples")
+        dv = lambda t: None if t is None else t.to(self.device, dtype=torch.float32).contiguous()
+        pts, ldmk_t, tgt, params = dv(pts), dv(ldmk_t), dv(tgt), dv(params)
+        if tuple(params.shape) != (self.cfg.m, self.p_stride) or not params.is_contiguous():
+            full = torch.zeros(self.cfg.m, self.p_stride, device=self.device, dtype=torch.float32)
+            full[:, :self.P] = params[:, :self.P]
+            params = full
+        job = dict(slot=slot, params=params, K=K, S=S, T=0 if tgt is None else tgt.shape[0],
+                   src=pts[K:] if S else None, ldmk_s=pts if K else None, ldmk_t=ldmk_t if K else None, tgt=tgt)
+        self.load_jobs([job])
+        self._keep = (job, pts)                    # keep the inputs alive until the next load
 
     def park(self, slot):
         """Mark a slot as finished (empty)."""
-        _, parked = self._templates()
-        self.state[self.tick & 1, slot].copy_(parked, non_blocking=True)
+        self.load_jobs([dict(slot=slot)])
+
+    def park_all(self):
+        self.load_jobs([dict(slot=s) for s in range(self.B)])
 
     def run_ticks(self, n_ticks):
         N.check(self.lib.ndp_engine_run(ctypes.byref(self.c_engine), self.tick, int(n_ticks),

@@ -89,6 +89,47 @@ def pyramid_fwd(desc: LayerDesc, m, k0, store, x):
     return out
 
 
+def pyramid_fwd_batch(desc: LayerDesc, m, k0, jobs, device=None):
+    """jobs: [(store [m,p_stride], x [n,3], shift_in [>=3] | None, shift_out [>=3] | None)] -> [x_out [n,3]]: every
+    cloud through its whole pyramid in ONE launch per 32 jobs; x_out = pyramid(x - shift_in) + shift_out."""
+    if not jobs:
+        return []
+    arr = (N.WarpJob * len(jobs))()
+    outs = []
+    stride = None
+    for q, (store, x, s_in, s_out) in zip(arr, jobs):
+        _chk(store, "store"); _chk(x, "x")
+        if s_in is not None:
+            _chk(s_in, "shift_in")
+        if s_out is not None:
+            _chk(s_out, "shift_out")
+        if stride is None:
+            stride = store.stride(0)
+        elif stride != store.stride(0):
+            raise N.NdpError("pyramid_fwd_batch: all stores must share one row stride")
+        out = torch.empty_like(x)
+        outs.append(out)
+        q.params, q.x, q.x_out = store.data_ptr(), x.data_ptr(), out.data_ptr()
+        q.shift_in = s_in.data_ptr() if s_in is not None else None
+        q.shift_out = s_out.data_ptr() if s_out is not None else None
+        q.n = x.shape[0]
+    cd = desc.c_struct()
+    dev = device if device is not None else jobs[0][1].device
+    N.check(N.lib().ndp_pyramid_fwd_batch(ctypes.byref(cd), int(m), int(k0), int(stride), arr, len(jobs),
+                                          N.stream_ptr(dev)), "ndp_pyramid_fwd_batch")
+    return outs
+
+
+def pair_means(src, tgt, out=None):
+    """-> means [8] on the device: [0:3] mean of src, [4:7] mean of tgt (registration.py:150-153)."""
+    _chk(src, "src"); _chk(tgt, "tgt")
+    if out is None:
+        out = torch.empty(8, device=src.device, dtype=torch.float32)
+    N.check(N.lib().ndp_pair_means(_p(src), src.shape[0], _p(tgt), tgt.shape[0], _p(out), N.stream_ptr(src.device)),
+            "ndp_pair_means")
+    return out
+
+
 def chamfer_nn(x, y):
     _chk(x, "x"); _chk(y, "y")
     S, T = x.shape[0], y.shape[0]

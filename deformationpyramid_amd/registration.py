@@ -30,9 +30,25 @@ from .nets import init_pyramid_store
 
 
 class _Prepared:
-    """Everything one pair needs on the device before it enters an engine slot."""
-    __slots__ = ("src_centered", "tgt_mean", "pts", "K", "S", "ldmk_t", "tgt_sample", "desc", "store", "result",
-                 "state", "src_pcd")
+    """Everything one pair needs on the device before it enters an engine slot: the raw clouds, their means, the
+    freshly initialised pyramid and the sampling permutations (one pinned upload), optional landmarks."""
+    __slots__ = ("src_pcd", "tgt_pcd", "means", "buf", "store", "perm_s", "perm_t", "K", "S", "T", "ldmk_s", "ldmk_t",
+                 "desc", "result", "state")
+
+    def tensors(self):
+        return [t for t in (self.src_pcd, self.tgt_pcd, self.means, self.buf, self.ldmk_s, self.ldmk_t) if t is not None]
+
+    def load_job(self, slot):
+        return dict(slot=slot, params=self.store, K=self.K, S=self.S, T=self.T, src=self.src_pcd, tgt=self.tgt_pcd,
+                    perm_s=self.perm_s, perm_t=self.perm_t, ldmk_s=self.ldmk_s, ldmk_t=self.ldmk_t, means=self.means)
+
+    def warp_job(self, store):
+        return (store, self.src_pcd, self.means, self.means[4:])
+
+    def release(self):
+        """Drop the device staging once the final warp has been enqueued (the allocator keeps the memory alive for
+        the streams the tensors were recorded on)."""
+        self.buf = self.store = self.perm_s = self.perm_t = self.tgt_pcd = self.ldmk_s = self.ldmk_t = None
 
 
 class Registration:
@@ -68,9 +84,9 @@ class Registration:
         prep = self._prepare(self.src_pcd, self.tgt_pcd, self.landmarks)
         self.src_pcd = prep.src_pcd
         eng = self._engine(1, prep)
-        eng.load(0, prep.pts, prep.K, prep.S, prep.ldmk_t, prep.tgt_sample, prep.store)
+        eng.load_jobs([prep.load_job(0)])
         st = eng.run_until_done(chunk=32)[0]
-        warped = self._finish(eng, 0, prep, st)
+        warped = self._finish(eng, [(0, prep)])[0]
         self.last_state = st
         iter_cnt = {lvl: int(st.evals_per_level[lvl]) for lvl in range(self.config.m)}
         if timer is not None:
@@ -131,24 +147,24 @@ class Registration:
             if ev is not None:
                 cur = torch.cuda.current_stream(dev)
                 cur.wait_event(ev)
-                for name in ("src_centered", "tgt_mean", "pts", "ldmk_t", "tgt_sample", "src_pcd", "store"):
-                    t = getattr(p, name)
-                    if t is not None:
-                        t.record_stream(cur)         # allocated on the producer's stream, consumed here
-                        t.record_stream(fin_stream)
+                fin_stream.wait_event(ev)
+                for t in p.tensors():                # allocated on the producer's stream, consumed on these two
+                    t.record_stream(cur)
+                    t.record_stream(fin_stream)
             else:
-                for name in ("src_centered", "tgt_mean"):
-                    getattr(p, name).record_stream(fin_stream)
+                for t in p.tensors():
+                    t.record_stream(fin_stream)
             preps[i] = p
             return i, p
 
         first = next_prepared()
         B = min(slots, len(pairs))
-        eng = self._engine(B, first[1], n_hint=self.config.samples + (first[1].K if first[1].K else 0))
-        for slot in range(B):
-            eng.park(slot)
+        eng = self._engine(B, first[1], n_hint=self.config.samples + first[1].K)
+        eng.park_all()
         # Pipelined control loop: the states of chunk k are read back while chunk k+1 runs, so the GPU
         # never waits for the host; a slot that finishes in chunk k is refilled before chunk k+2.
+        # Refills of one round go up in ONE launch (k_eng_load), the final all-point warps of the pairs that
+        # finished in one chunk in ONE launch (k_pyramid_fwd) on a side stream.
         fin_done = {}                                            # slot -> event: its parameters have been consumed
         main = torch.cuda.current_stream(dev)
         active, free, exhausted = {}, list(range(B)), False      # active: slot -> (pair index, first valid snapshot)
@@ -157,6 +173,7 @@ class Registration:
         seq = 0                                                  # snapshots taken so far
         pending = None
         while True:
+            jobs = []
             while free and not exhausted:
                 if nxt is None:
                     nxt = next_prepared()
@@ -168,8 +185,10 @@ class Registration:
                 slot = free.pop()
                 if slot in fin_done:
                     main.wait_event(fin_done.pop(slot))          # the previous tenant's final warp read these params
-                eng.load(slot, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.store)
+                jobs.append(p.load_job(slot))
                 active[slot] = (i, seq)                          # snapshots >= seq see this pair in the slot
+            if jobs:
+                eng.load_jobs(jobs)
             if not active and pending is None:
                 break
             handle = None
@@ -180,25 +199,28 @@ class Registration:
             if pending is not None:
                 (h, hseq) = pending
                 states = eng.wait_snapshot(h)
+                done = []
                 for slot in list(active):
                     i, valid_from = active[slot]
                     st = states[slot]
                     if hseq < valid_from or st.level < m:
                         continue
                     del active[slot]
-                    p = preps[i]
-                    # the snapshot proves every tick that touched this slot has completed: the final warp
-                    # needs no dependency on the main stream, only the slot's refill must wait for it
+                    preps[i].state = st
+                    done.append((slot, preps[i]))
+                    free.append(slot)
+                if done:
+                    # the snapshot proves every tick that touched these slots has completed: the final warp
+                    # needs no dependency on the main stream, only the slots' refill must wait for it
                     with torch.cuda.stream(fin_stream):
-                        frozen = eng.params[slot].clone()            # 1.25 MB device copy: the slot is free again
+                        outs = self._finish(eng, done, freeze=True)
                         ev = torch.cuda.Event()
                         ev.record(fin_stream)
-                        p.result = self._finish(eng, slot, p, st, store=frozen)
-                    fin_done[slot] = ev
-                    p.result.record_stream(main)
-                    p.state = st
-                    eng.park(slot)
-                    free.append(slot)
+                    for (slot, p), out in zip(done, outs):
+                        fin_done[slot] = ev
+                        out.record_stream(main)
+                        p.result = out
+                        p.release()
             pending = handle
         main.wait_stream(fin_stream)
         self.last_states = [p.state for p in preps]
@@ -226,6 +248,9 @@ class Registration:
                          w_reg=float(c.w_reg), early_stop=True)
 
     def _prepare(self, src_pcd, tgt_pcd, landmarks):
+        """Host side of registration.py:133-164 for one pair: RNG replay of the pyramid initialisation and of the two
+        sampling permutations into ONE pinned buffer, one asynchronous upload, one launch for the two cloud means.
+        Centring, sampling and the slot fill itself happen on the device (k_eng_load)."""
         c = self.config
         dev = self._dev()
         if c.depth != 3 or c.width != 128:
@@ -237,62 +262,60 @@ class Registration:
                            nonrigidity=gate)                                        # engine: "levels > 0 gated"
         level0 = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format)
         stride = (p.desc.param_count + 63) // 64 * 64
-        host = self._pinned_store(c.m, stride)                                     # reused pinned staging buffer
-        init_pyramid_store([level0] + [p.desc] * (c.m - 1), c.depth, stride, out=host)   # nets.py:26
-        p.store = host.to(dev, non_blocking=True)                                  # async upload on the current stream
-        self._pin_busy.append((host, torch.cuda.Event()))
-        self._pin_busy[-1][1].record(torch.cuda.current_stream(dev))
-        src_pcd = src_pcd.to(dev).float()
-        tgt_pcd = tgt_pcd.to(dev).float()
-        p.src_pcd = src_pcd
-        src_mean = src_pcd.mean(dim=0, keepdim=True)                              # :150-153
-        p.tgt_mean = tgt_pcd.mean(dim=0, keepdim=True)
-        p.src_centered = (src_pcd - src_mean).contiguous()
-        tgt_c = tgt_pcd - p.tgt_mean
+        n_par = c.m * stride
+        samples = int(c.samples)
+        host = self._pinned_store(n_par + 2 * samples)                             # reused pinned staging buffer
+        init_pyramid_store([level0] + [p.desc] * (c.m - 1), c.depth, stride, out=host[:n_par].view(c.m, stride))   # nets.py:26
+        src_pcd = src_pcd.to(dev, non_blocking=True).float().contiguous()
+        tgt_pcd = tgt_pcd.to(dev, non_blocking=True).float().contiguous()
+        p.src_pcd, p.tgt_pcd = src_pcd, tgt_pcd
         perm_s = torch.randperm(src_pcd.shape[0])                                 # :156-159 (CPU RNG)
         perm_t = torch.randperm(tgt_pcd.shape[0])
-        s_sample = p.src_centered[perm_s[: c.samples].to(dev)]
-        t_sample = tgt_c[perm_t[: c.samples].to(dev)]
+        ns, nt = min(samples, perm_s.shape[0]), min(samples, perm_t.shape[0])
+        hi = host[n_par:].view(torch.int32)
+        hi[:ns] = perm_s[:ns]
+        hi[samples:samples + nt] = perm_t[:nt]
+        p.buf = host.to(dev, non_blocking=True)                                    # async upload on the current stream
+        self._pin_busy.append((host, torch.cuda.Event()))
+        self._pin_busy[-1][1].record(torch.cuda.current_stream(dev))
+        p.store = p.buf[:n_par].view(c.m, stride)
+        di = p.buf[n_par:].view(torch.int32)
+        p.perm_s, p.perm_t = di[:ns], di[samples:samples + nt]
+        p.means = ops.pair_means(src_pcd, tgt_pcd)                                # :150-153
+        p.ldmk_s = p.ldmk_t = None
         if landmarks is not None:
-            ls = landmarks[0].to(dev).float() - src_mean                          # :162-164
-            p.ldmk_t = (landmarks[1].to(dev).float() - p.tgt_mean).contiguous()
-            p.K = ls.shape[0]
+            p.ldmk_s = landmarks[0].to(dev).float().contiguous()                  # :162-164 (centred on the device)
+            p.ldmk_t = landmarks[1].to(dev).float().contiguous()
+            p.K = p.ldmk_s.shape[0]
             if c.w_cd > 0:
-                p.S = s_sample.shape[0]
-                p.pts = torch.cat([ls, s_sample]).contiguous()                    # :190
-                p.tgt_sample = t_sample.contiguous()
+                p.S, p.T = ns, nt                                                  # :190
             else:
-                p.S = 0
-                p.pts = ls.contiguous()
-                p.tgt_sample = None
+                p.S, p.T = 0, 0
         else:
-            p.K, p.S, p.ldmk_t = 0, s_sample.shape[0], None
-            p.pts = s_sample.contiguous()
-            p.tgt_sample = t_sample.contiguous()
+            p.K, p.S, p.T = 0, ns, nt
         p.result = p.state = None
         return p
 
-    def _pinned_store(self, m, stride):
-        """A pinned [m, stride] host buffer whose previous upload has completed (small ring, allocated once:
-        cudaHostAlloc costs milliseconds)."""
+    def _pinned_store(self, numel):
+        """A pinned float32 host buffer of `numel` elements whose previous upload has completed (small ring, allocated
+        once: hipHostMalloc costs milliseconds)."""
         if not hasattr(self, "_pin_free"):
             self._pin_free, self._pin_busy = [], []
         while self._pin_busy and self._pin_busy[0][1].query():
             self._pin_free.append(self._pin_busy.pop(0)[0])
         for i, buf in enumerate(self._pin_free):
-            if buf.shape == (m, stride):
+            if buf.numel() == numel:
                 return self._pin_free.pop(i)
         if len(self._pin_busy) >= 64:                                               # bound the ring: wait for the oldest
             host, ev = self._pin_busy.pop(0)
             ev.synchronize()
-            if host.shape == (m, stride):
+            if host.numel() == numel:
                 return host
-        return torch.empty(m, stride, dtype=torch.float32).pin_memory()
+        return torch.empty(numel, dtype=torch.float32).pin_memory()
 
     def _engine(self, B, like, n_hint=0):
         n_cap = ops.cap(max(like.K + like.S, n_hint))
-        t_cap = ops.cap(max(0 if like.tgt_sample is None else like.tgt_sample.shape[0],
-                            self.config.samples if like.S else 0))
+        t_cap = ops.cap(max(like.T, self.config.samples if like.S else 0))
         cfg = self._opt_config(like.K > 0)
         desc = like.desc
         key = (B, n_cap, t_cap, desc, tuple(sorted(vars(cfg).items())))
@@ -301,10 +324,13 @@ class Registration:
             self._engines[key] = BatchedEngine(desc, cfg, B, n_cap, t_cap, self._dev())
         return self._engines[key]
 
-    def _finish(self, eng, slot, prep, st, store=None):
-        """registration.py:253-262: warp ALL source points through the optimised pyramid, add tgt_mean."""
+    def _finish(self, eng, done, freeze=False):
+        """registration.py:253-262 for every (slot, prepared pair) of `done`, in one launch: ALL source points through
+        the optimised pyramid (centring by the source mean and adding the target mean happen in the kernel).
+        freeze=True first snapshots the slots' parameters so that the slots can be refilled at once."""
         c = self.config
-        if store is None:
-            store = eng.params[slot]                                              # [m, p_stride] on device
-        warped = ops.pyramid_fwd(prep.desc, c.m, c.k0, store, prep.src_centered)
-        return warped + prep.tgt_mean
+        jobs = []
+        for slot, prep in done:
+            store = eng.params[slot].clone() if freeze else eng.params[slot]      # [m, p_stride] on device
+            jobs.append(prep.warp_job(store))
+        return ops.pyramid_fwd_batch(done[0][1].desc, c.m, c.k0, jobs, device=self._dev())

@@ -61,9 +61,31 @@ int ndp_grad_reduce(const float *grads_part, int n_part, int p_stride, int P, fl
 /* Whole pyramid forward, levels 0..m-1 (Deformation_Pyramid.warp, nets.py:36-48; the final
  * inference warp of registration.py:254-255).  params_all: level l at params_all + l*p_stride.
  * desc->nonrigidity = 1 means "every level but the first carries the gate" (nets.py:26).
- * tmp [n][3] scratch.                                                                           */
+ * tmp: unused (kept for ABI stability; may be NULL).                                              */
 int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const float *params_all, int p_stride,
                     const float *x, int n, float *x_out, float *tmp, void *stream);
+
+/* Batched, single-launch form of the final inference warp: every job is one cloud pushed through all m
+ * levels inside ONE kernel (grid = tiles x jobs; a workgroup keeps its 64 points in LDS from level to
+ * level, so there is no intermediate HBM traffic and one launch fills the chip with several pairs).
+ * Folds the centring and the un-centring of registration.py:150-153 / :258:
+ *     x_out = pyramid(x - shift_in) + shift_out          (either shift may be NULL).
+ * `jobs` is a HOST array (copied into the kernel arguments); all jobs share desc / m / k0 / p_stride. */
+typedef struct ndp_warp_job {
+    const float *params;             /* [m][p_stride] */
+    const float *x;                  /* [n][3] */
+    float *x_out;                    /* [n][3] (may alias x) */
+    const float *shift_in;           /* [3] device, or NULL */
+    const float *shift_out;          /* [3] device, or NULL */
+    int n, pad;
+} ndp_warp_job;
+#define NDP_MAX_WARP_JOBS 32
+int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_stride,
+                          const ndp_warp_job *jobs, int n_jobs, void *stream);
+
+/* Per-cloud means (registration.py:150-153: src_pcd.mean(dim=0), tgt_pcd.mean(dim=0)); means[0..2] = source,
+ * means[4..6] = target (means[3], means[7] = 0).  Accumulated in double in a fixed order, rounded once.   */
+int ndp_pair_means(const float *src, int n_src, const float *tgt, int n_tgt, float *means, void *stream);
 
 /* Exact brute-force 1-NN in both directions (pytorch3d knn_points K=1 as called at loss.py:177-178):
  * d2x[i] = min_j |x_i - y_j|^2 (fma chain over x,y,z), idx_x[i] = lowest argmin; same for y->x.  */
@@ -128,11 +150,11 @@ typedef struct ndp_engine {
     float w_cd, trunc;
     float adam_w1, adam_b2, adam_w2, adam_eps;
     float w_reg, pad_f;              /* nonrigidity BCE weight (registration.py:216-220)         */
-    const ndp_pair_geom *geom;       /* [B]                                                     */
+    ndp_pair_geom *geom;             /* [B]                                                     */
     ndp_pair_state *state;           /* [2][B] double-buffered by tick parity                   */
     float *pts;                      /* [B][2][n_cap][3]  landmarks first, then samples         */
-    const float *ldmk_t;             /* [B][n_cap][3]                                           */
-    const float *tgt;                /* [B][t_cap][3]                                           */
+    float *ldmk_t;                   /* [B][n_cap][3]                                           */
+    float *tgt;                      /* [B][t_cap][3]                                           */
     float *params;                   /* [B][m][p_stride]                                        */
     float *gpart;                    /* [B][G][p_stride]                                        */
     float *adam_m, *adam_v;          /* [B][p_stride]                                           */
@@ -148,6 +170,24 @@ typedef struct ndp_engine {
  * The caller initialises state[tick0 & 1] (level 0, iter 0, break_counter 0, loss_prev 1e6, cur 0).
  * Asynchronous on `stream`; read state[(tick0 + n_ticks) & 1] after synchronising.              */
 int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream);
+
+/* Slot (re)fill in one launch for several pairs (registration.py:150-164: centring, sampling by the
+ * permutation prefix, landmark centring; :133-140 the freshly initialised pyramid; :176 fresh Adam state):
+ *   pts[slot][0][i]   = i < K ? ldmk_s[i] - mean_s : src[perm_s[i-K]] - mean_s      (i < K+S, rest zero)
+ *   ldmk_t[slot][k]   = ldmk_t[k] - mean_t ;  tgt[slot][j] = tgt[perm_t[j]] - mean_t  (j < T)
+ *   params[slot]      = params ; adam_m = adam_v = 0 ; geom = (K,S,T) ; state[tick & 1][slot] = fresh
+ * perm_* NULL = identity, means NULL = no centring.  A job with params == NULL parks the slot (level = m).
+ * `jobs` is a HOST array (copied into the kernel arguments); at most NDP_MAX_LOAD_JOBS per call.       */
+typedef struct ndp_load_job {
+    const float *src, *tgt;          /* raw clouds [n][3] (device) */
+    const int *perm_s, *perm_t;      /* first S / T entries of the sampling permutations (device int32) or NULL */
+    const float *ldmk_s, *ldmk_t;    /* [K][3] or NULL */
+    const float *params;             /* [m][p_stride] initial parameters (device) or NULL = park */
+    const float *means;              /* [8] from ndp_pair_means, or NULL */
+    int slot, K, S, T;
+} ndp_load_job;
+#define NDP_MAX_LOAD_JOBS 16
+int ndp_engine_load(const ndp_engine *e, int tick, const ndp_load_job *jobs, int n_jobs, void *stream);
 
 /* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[7] (HOST memory)
  * receives the summed durations of the forward, NN, loss/gradient, backward-heads, backward-2, backward-1 and

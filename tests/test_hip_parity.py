@@ -364,3 +364,109 @@ def test_config5_lndp_sizes(dev):
         assert st.level == 10 and st.total_steps == 30
         assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
         assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+
+
+# ------------------------------------------------------------------------------ fused pair preparation / final warp
+@pytest.mark.parametrize("tag", ["se3aa", "sim3eu", "se36d", "sflow"])
+def test_pyramid_fwd_batch_equals_level_chain_bitwise(dev, tag):
+    """The single-launch pyramid (points carried in LDS between levels) must reproduce the level-by-level kernel
+    bit for bit, for several clouds of different sizes in one launch, with the centring shifts folded in."""
+    from deformationpyramid_amd import ops
+    m = 5
+    pyrs = [seeded_pyramid(40 + j, m=m, **VARIANTS[tag]) for j in range(3)]
+    for pyr in pyrs:
+        for lvl in range(m):
+            scale_heads(pyr, lvl, 20.0)
+    sizes = [1, 777, 2048]
+    jobs, want = [], []
+    for j, (pyr, n) in enumerate(zip(pyrs, sizes)):
+        x = (cloud(n, 60 + j) + 0.3).to(dev)
+        s_in = torch.tensor([0.31, 0.29, 0.33, 0.0], device=dev)
+        s_out = torch.tensor([-1.5, 2.0, 0.25, 0.0], device=dev)
+        store = pyr.store.to(dev)
+        jobs.append((store, x, s_in if j != 1 else None, s_out if j != 1 else None))
+        cur = x - s_in[:3] if j != 1 else x
+        for lvl in range(m):
+            cur = ops.level_fwd(pyr.descs[lvl], store[lvl], lvl, K0, cur.contiguous())
+        want.append(cur + s_out[:3] if j != 1 else cur)
+    outs = ops.pyramid_fwd_batch(pyrs[0].descs[0], m, K0, jobs)
+    for got, ref in zip(outs, want):
+        assert torch.equal(got, ref)
+    # and the single-cloud ABI entry goes through the same kernel
+    one = ops.pyramid_fwd(pyrs[1].descs[0], m, K0, jobs[1][0], jobs[1][1])
+    assert torch.equal(one, want[1])
+
+
+def test_pyramid_fwd_batch_more_jobs_than_one_launch_and_gated_levels(dev, golden):
+    from deformationpyramid_amd import ops
+    m = 3
+    pyr = seeded_pyramid(5, m=m, nonrigidity_est=True, **VARIANTS["se3aa"])
+    store = pyr.store.to(dev)
+    xs = [cloud(64 + 3 * j, 300 + j).to(dev) for j in range(40)]          # > NDP_MAX_WARP_JOBS
+    outs = ops.pyramid_fwd_batch(pyr.descs[1], m, K0, [(store, x, None, None) for x in xs])
+    descs = [cdesc(dd) for dd in pyr.descs]
+    pa = np.concatenate([pyr.store[i, :dd.param_count].numpy() for i, dd in enumerate(pyr.descs)])
+    for j in (0, 17, 39):
+        ref = O().pyramid_fwd(descs, K0, pa, xs[j].cpu().numpy(), nthreads=2)
+        assert np.abs(outs[j].cpu().numpy() - ref).max() < 1e-5
+
+
+def test_pair_means_is_the_correctly_rounded_mean(dev):
+    from deformationpyramid_amd import ops
+    g = torch.Generator().manual_seed(3)
+    src = torch.rand(8192, 3, generator=g) * 4 - 1
+    tgt = torch.rand(5001, 3, generator=g) * 0.1 + 7
+    got = ops.pair_means(src.to(dev), tgt.to(dev)).cpu().numpy()
+    assert np.array_equal(got[:3], src.double().mean(0).float().numpy())
+    assert np.array_equal(got[4:7], tgt.double().mean(0).float().numpy())
+    assert got[3] == 0 and got[7] == 0
+
+
+def test_engine_load_jobs_centres_samples_and_resets_the_slot(dev):
+    """k_eng_load against the torch statement of registration.py:150-164 (bit-exact: one subtraction per value)."""
+    from deformationpyramid_amd import ops
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    from deformationpyramid_amd import _native as N
+    m = 2
+    pyr = seeded_pyramid(9, m=m, **VARIANTS["se3aa"])
+    d = pyr.descs[0]
+    eng = BatchedEngine(d, OptConfig(m=m, iters=4, early_stop=False), 3, n_cap=320, t_cap=256, device=dev)
+    eng.park_all()
+    eng.adam_m.fill_(3.0); eng.adam_v.fill_(4.0); eng.pts.fill_(9.0)
+    g = torch.Generator().manual_seed(1)
+    jobs, want = [], []
+    for b, (K, S, T) in enumerate([(0, 300, 250), (20, 190, 256), (7, 0, 0)]):
+        src = (torch.rand(1000, 3, generator=g) + 0.5).to(dev)
+        tgt = (torch.rand(900, 3, generator=g) - 2.0).to(dev)
+        ps = torch.randperm(1000, generator=g)[:max(S, 1)].to(torch.int32).to(dev)
+        pt = torch.randperm(900, generator=g)[:max(T, 1)].to(torch.int32).to(dev)
+        ls = torch.rand(max(K, 1), 3, generator=g).to(dev)
+        lt = torch.rand(max(K, 1), 3, generator=g).to(dev)
+        means = ops.pair_means(src, tgt)
+        store = torch.zeros(m, eng.p_stride, device=dev)
+        store[:, :eng.P] = pyr.store[:, :eng.P].to(dev) + b
+        jobs.append(dict(slot=2 - b, params=store, K=K, S=S, T=T, src=src, tgt=tgt, perm_s=ps, perm_t=pt,
+                         ldmk_s=ls if K else None, ldmk_t=lt if K else None, means=means))
+        pts = torch.cat([ls[:K] - means[:3], src[ps[:S].long()] - means[:3]]) if K + S else None
+        want.append((2 - b, K, S, T, pts, lt[:K] - means[4:7], tgt[pt[:T].long()] - means[4:7], store))
+    eng.load_jobs(jobs)
+    torch.cuda.synchronize()
+    states = eng.read_states()
+    for slot, K, S, T, pts, lt, tg, store in want:
+        n = K + S
+        assert torch.equal(eng.pts[slot, 0, :n], pts)
+        assert torch.count_nonzero(eng.pts[slot, 0, n:]) == 0
+        assert torch.equal(eng.ldmk_t[slot, :K], lt) and torch.equal(eng.tgt[slot, :T], tg)
+        assert torch.equal(eng.params[slot], store)
+        assert torch.count_nonzero(eng.adam_m[slot]) == 0 and torch.count_nonzero(eng.adam_v[slot]) == 0
+        assert eng.geom[slot].tolist() == [K, S, T, 0]
+        st = states[slot]
+        assert (st.level, st.iter, st.break_counter, st.adam_t, st.cur, st.total_steps) == (0, 0, 0, 0, 0, 0)
+        assert st.loss_prev == 1e6
+    eng.park(1)
+    torch.cuda.synchronize()
+    assert eng.read_states()[1].level == m and eng.read_states()[0].level == 0
+    # invalid jobs are refused by the C ABI, not silently clipped
+    bad = dict(jobs[0]); bad["S"] = 400
+    with pytest.raises((ValueError, N.NdpError)):
+        eng.load_jobs([bad])

@@ -35,6 +35,10 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_native.PairGeom) == 16
     assert _native.Engine.break_threshold_ratio.offset % 8 == 0
     assert _native.Engine.geom.offset % 8 == 0
+    assert ctypes.sizeof(_native.WarpJob) == 48 and ctypes.sizeof(_native.LoadJob) == 80     # 5 / 8 pointers + 2 / 4 ints
+    header = open(os.path.join(ROOT, "include", "ndp_hip.h")).read()
+    assert int(re.search(r"#define NDP_MAX_WARP_JOBS (\d+)", header).group(1)) == _native.MAX_WARP_JOBS
+    assert int(re.search(r"#define NDP_MAX_LOAD_JOBS (\d+)", header).group(1)) == _native.MAX_LOAD_JOBS
 
 
 def test_invalid_arguments_are_rejected_without_a_gpu():
@@ -47,6 +51,9 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     ok = LayerDesc().c_struct()
     assert L.ndp_level_fwd(ctypes.byref(ok), None, 0, -8, None, 5, None, None, None, None, None) == -1
     assert L.ndp_chamfer_nn_fwd(None, 0, None, 0, None, None, None, None, None) == -1
+    assert L.ndp_pair_means(None, 0, None, 0, None, None) == -1
+    assert L.ndp_pyramid_fwd_batch(ctypes.byref(ok), 9, -8, 8, None, 1, None) == -1            # p_stride < P
+    assert L.ndp_engine_load(None, 0, None, 0, None) == -1
     deep = LayerDesc(n_hidden=3).c_struct()                     # depth 4: kernels are specialised for depth 3
     assert L.ndp_level_fwd(ctypes.byref(deep), None, 0, -8, None, 0, None, None, None, None, None) == -2
     for fmt in ("axis_angle", "euler", "quaternion", "6D"):     # n = 0 is a valid no-op for every served variant

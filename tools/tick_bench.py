@@ -20,7 +20,7 @@ for i in range(B):
     preps.append(model._prepare(s.to(dev), t.to(dev), None))
 eng = model._engine(B, preps[0])
 for b, p in enumerate(preps):
-    eng.load(b, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.store)
+    eng.load_jobs([p.load_job(b)])
 eng.run_ticks(4)
 torch.cuda.synchronize()
 ms = eng.run_ticks_timed(ticks)

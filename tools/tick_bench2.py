@@ -24,7 +24,7 @@ for e in range(E):
         preps.append(model._prepare(s.to(dev), t.to(dev), None))
     eng = BatchedEngine(preps[0].desc, model._opt_config(False), B, 2048, 2048, dev, G=G)
     for b, p in enumerate(preps):
-        eng.load(b, p.pts, p.K, p.S, p.ldmk_t, p.tgt_sample, p.store)
+        eng.load_jobs([p.load_job(b)])
     engs.append(eng); streams.append(torch.cuda.Stream(dev))
 torch.cuda.synchronize()
 def run(n, chunk=1):
