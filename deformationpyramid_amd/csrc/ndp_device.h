@@ -17,6 +17,7 @@
 #define NDP_HROW   24           // row stride of the saved per-point record: 16 head outputs + 6 posenc values + 2 pad
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct HeadCfg {
     int motion, rotfmt, n_rot, row_scale, row_trn, nh;

@@ -25,25 +25,71 @@
 #include <cstring>
 
 #define MFMA32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// -DNDP_PHASE_TIMING: experiment builds only (tools/phase_timing.py) -- thread 0 of every workgroup adds the shader
+// cycles it spent in each phase of a tile to g_phase[]; compiled out of the product library.
+#ifdef NDP_PHASE_TIMING
+__device__ unsigned long long g_phase[64];
+__shared__ unsigned long long pt_acc[12];                 // per-workgroup accumulators (LDS: no global traffic per stamp)
+#define PT_INIT                                           \
+    do {                                                  \
+        if (threadIdx.x < 12) pt_acc[threadIdx.x] = 0;    \
+        __syncthreads();                                  \
+    } while (0)
+#define PT_FLUSH(base)                                                                           \
+    do {                                                                                         \
+        __syncthreads();                                                                         \
+        if (threadIdx.x < 12 && pt_acc[threadIdx.x]) atomicAdd(&g_phase[(base) + threadIdx.x], pt_acc[threadIdx.x]); \
+    } while (0)
+#define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter()
+#define PT(id)                                                                  \
+    do {                                                                        \
+        if (threadIdx.x == 0) {                                                 \
+            const unsigned long long pt_now = __builtin_readcyclecounter();     \
+            pt_acc[(id) % 12] += pt_now - pt_last;                              \
+            pt_last = pt_now;                                                   \
+        }                                                                       \
+    } while (0)
+#else
+#define PT_INIT
+#define PT_FLUSH(base)
+#define PT_DECL
+#define PT(id)
+#endif
+
+// Two workgroups share a CU.  Launched together they fall into lock-step (both in their MFMA phase, then both
+// in their memory phase), which leaves the matrix pipe idle during the memory phases; the workgroup that got
+// the odd wave slot therefore starts half a tile period late (experiment: -DNDP_DESYNC=<sleeps of 8k cycles>).
+__device__ __forceinline__ void desync_odd_slot(int sleeps) {
+#ifdef NDP_DESYNC_BY_ID
+    const unsigned wave_slot = (blockIdx.y * gridDim.x + blockIdx.x) >= 256;
+#else
+    const unsigned wave_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));   // HW_ID.wave_id
+#endif
+    if (wave_slot & 1)
+        for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+}
+#ifndef NDP_DESYNC
+#define NDP_DESYNC 0
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // LDS carve (floats).  All scratch lives in the dynamic region (16-byte aligned offsets).
 // ------------------------------------------------------------------------------------------------
+#define NDP_WHROWS 12                     /* head rows staged in LDS (at most 6 + 1 + 3 + 1 = 11 are used) */
 enum : int {
     L_BUFA = 0,
     L_BUFB = L_BUFA + 64 * NDP_LD,
-    L_PE = L_BUFB + 64 * NDP_LD,          // [64][9] posenc (stride 9: conflict-free MFMA A-operand reads)
-    L_XS = L_PE + 64 * 9,                 // [64][4] level input x
-    L_WH = L_XS + 64 * 4,                 // [12][128] head weights (at most 6+1+3+1 = 11 rows)
-    L_BH = L_WH + 12 * NDP_W,             // [16]
-    L_HO = L_BH + NDP_NHMAX,              // [64][16] head outputs / d_o
-    L_XW = L_HO + 64 * NDP_NHMAX,         // [64][4] warped x (backward)
-    L_G = L_XW + 64 * 4,                  // [4][64][4] gradient partials (backward)
-    L_RED = L_G + 4 * 64 * 4,             // [256] reduction scratch
-    L_TOTAL = L_RED + 256
+    L_HO = L_BUFB,                        // [64][16] head outputs: reuses bufB, which is dead after layer 2
+    L_PE = L_BUFB + 64 * NDP_LD,          // 2 x [64][9] posenc, double-buffered across tiles (stride 9: conflict-free)
+    L_XS = L_PE + 2 * 64 * 9,             // 2 x [64][4] level input x
+    L_WH = L_XS + 2 * 64 * 4,             // [12][NDP_LD] head weights
+    L_BH = L_WH + NDP_WHROWS * NDP_LD,    // [16]
+    L_FWD_TOTAL = L_BH + NDP_NHMAX
 };
-static constexpr int kSmemBytes = L_TOTAL * 4;
-static constexpr int kSmemFwdBytes = L_XW * 4;     // forward uses the carve up to the head outputs only
+static constexpr int kSmemFwdBytes = L_FWD_TOTAL * 4;     // 80 640 B: two workgroups per CU
+static_assert(2 * kSmemFwdBytes <= 160 * 1024, "forward LDS carve must allow two workgroups per CU");
 
 struct LevelJob {
     const float *params;
@@ -139,8 +185,9 @@ struct FwdWeights {
     float bias0, bias1, bias2;
 };
 
-// Loads a level's weights into registers and stages its head matrix in LDS.  The caller must pass a barrier
-// before the first tile's head phase (the tile's own barriers do) and after the last one before reloading.
+// Loads a level's weights into registers and stages its head matrix in LDS (row stride NDP_LD, so that the
+// 16x16x4 MFMA B-operand reads are conflict-free).  The caller must pass a barrier before the first head phase
+// (the tile's own barriers do) and after the last one before reloading.
 __device__ __forceinline__ void fwd_load_weights(const HeadCfg &hc, const float *P, float *sm, FwdWeights &fw) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
     float *whs = sm + L_WH, *bhs = sm + L_BH;
@@ -158,7 +205,8 @@ __device__ __forceinline__ void fwd_load_weights(const HeadCfg &hc, const float 
 #pragma unroll
     for (int ks = 0; ks < 3; ++ks) fw.w0b[ks] = W0[(32 * wv + l31) * 6 + 2 * ks + h];
     fw.bias0 = b0[32 * wv + l31];
-    for (int i = t; i < 12 * NDP_W; i += 256) whs[i] = (i < hc.nh * NDP_W) ? Wh[i] : 0.f;
+    for (int i = t; i < NDP_WHROWS * NDP_W; i += 256)
+        whs[(i >> 7) * NDP_LD + (i & 127)] = (i < hc.nh * NDP_W) ? Wh[i] : 0.f;
     if (t < NDP_NHMAX) bhs[t] = (t < hc.nh) ? bh[t] : 0.f;
 }
 
@@ -174,30 +222,31 @@ struct TileIO {
     int n, plane;
 };
 
-// One 64-point tile through one level: posenc -> 3 layers on MFMA -> heads -> warp.  Ends with a barrier.
-__device__ __forceinline__ void fwd_tile(const HeadCfg &hc, const FwdWeights &fw, float freq, const TileIO &io,
-                                         int base, float *sm) {
+// level input of point `base + lane`, coordinate `axis` (zero beyond n)
+__device__ __forceinline__ float fwd_fetch_x(const TileIO &io, int base, int lane, int axis) {
+    const int p = base + lane;
+    if (p >= io.n) return 0.f;
+    const float xa = io.x_in[3 * (size_t)p + axis];
+    return io.shift_in ? xa - io.shift_in[axis] : xa;
+}
+
+// positional encoding (nets.py:164-177) of one coordinate of one point -> pe / xs of the given LDS set
+__device__ __forceinline__ void fwd_posenc(float xa, float freq, int lane, int axis, float *pe, float *xs, bool write_x) {
+    float sn, cs;
+    sincosf(xa * freq, &sn, &cs);
+    pe[lane * 9 + 2 * axis] = sn;
+    pe[lane * 9 + 2 * axis + 1] = cs;
+    if (write_x) xs[4 * lane + axis] = xa;
+}
+
+// One 64-point tile from its positional encoding (pe) to the scaled head outputs (ho, which reuses bufB):
+// 3 layers on the 32x32x2 MFMA, heads on the 16x16x4 MFMA; activations -> HBM.  Ends with a barrier.
+__device__ __forceinline__ void fwd_tile_core(const HeadCfg &hc, const FwdWeights &fw, const TileIO &io, int base,
+                                              float *sm, const float *pe) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
-    float *bufA = sm + L_BUFA, *bufB = sm + L_BUFB, *pe = sm + L_PE, *xs = sm + L_XS;
+    float *bufA = sm + L_BUFA, *bufB = sm + L_BUFB;
     float *whs = sm + L_WH, *bhs = sm + L_BH, *ho = sm + L_HO;
-    // ---- positional encoding (nets.py:164-177): thread (point = lane, axis = wave) for waves 0..2
-    if (wv < 3) {
-        const int p = base + lane;
-        float xa;
-        if (io.x_in) {
-            xa = p < io.n ? io.x_in[3 * p + wv] : 0.f;
-            if (io.shift_in) xa = p < io.n ? xa - io.shift_in[wv] : 0.f;
-            xs[4 * lane + wv] = xa;
-        } else {
-            xa = xs[4 * lane + wv];
-        }
-        const float phs = xa * freq;
-        float sn, cs;
-        sincosf(phs, &sn, &cs);
-        pe[lane * 9 + 2 * wv] = sn;
-        pe[lane * 9 + 2 * wv + 1] = cs;
-    }
-    __syncthreads();
+    PT_DECL;
     // ---- layer 0 (MFMA, bitwise the k = 0..5 fmaf chain starting from the bias) -> bufA
     {
         f32x16 acc0, acc1;
@@ -217,7 +266,9 @@ __device__ __forceinline__ void fwd_tile(const HeadCfg &hc, const FwdWeights &fw
             bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
         }
     }
+    PT(2);
     __syncthreads();
+    PT(3);
     // ---- layer 1 (MFMA) bufA -> bufB ; h0 goes to HBM as float4 rows while the matrix pipe works
     {
         f32x16 acc0, acc1;
@@ -233,7 +284,9 @@ __device__ __forceinline__ void fwd_tile(const HeadCfg &hc, const FwdWeights &fw
             bufB[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
         }
     }
+    PT(4);
     __syncthreads();
+    PT(5);
     // ---- layer 2 (MFMA) bufB -> bufA ; h1 -> HBM
     {
         f32x16 acc0, acc1;
@@ -249,65 +302,94 @@ __device__ __forceinline__ void fwd_tile(const HeadCfg &hc, const FwdWeights &fw
             bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
         }
     }
-    __syncthreads();
+    PT(6);
+    __syncthreads();                                                                          // bufB (h1) is dead from here
+    PT(7);
     if (io.act) store_tile_from_lds(bufA, io.act + (2 * (size_t)io.plane + base) * NDP_W);   // h2 -> HBM
-    // ---- heads (nets.py:117,125,146): thread (p = lane, jq = wave) computes heads jq, jq+4, ...
+    PT(11);
+    // ---- heads (nets.py:117,125,146) on the 16x16x4 MFMA: wave w owns points 16w..16w+15, the 16 columns are
+    //      the head rows (zero beyond nh).  A[p][k]: lane = p + 16*(k mod 4 group); D[p][j]: lane = j + 16*(p/4).
     {
-        const float *hrow = bufA + lane * NDP_LD;
-        for (int j = wv; j < hc.nh; j += 4) {
-            const float *wr = whs + j * NDP_W;
-            // four independent fmaf chains (k mod 4): a lone 128-long chain is pure FMA latency
-            float a0 = bhs[j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
-#pragma unroll 8
-            for (int k4 = 0; k4 < 32; ++k4) {
-                const float4 hv = *reinterpret_cast<const float4 *>(hrow + 4 * k4);
-                const float4 wv4 = *reinterpret_cast<const float4 *>(wr + 4 * k4);
-                a0 = fmaf(wv4.x, hv.x, a0);
-                a1 = fmaf(wv4.y, hv.y, a1);
-                a2 = fmaf(wv4.z, hv.z, a2);
-                a3 = fmaf(wv4.w, hv.w, a3);
-            }
-            ho[lane * NDP_NHMAX + j] = hc.mlp_scale * ((a0 + a1) + (a2 + a3));
-        }
-    }
-    __syncthreads();
-    // ---- warp (nets.py:119-129)
-    if (t < 64) {
-        const int p = base + t;
-        const float *o = ho + t * NDP_NHMAX;
-        if (io.heads) {
-            float *hr = io.heads + (size_t)p * NDP_HROW;
+        const int l15 = lane & 15, lk = lane >> 4;
+        f32x4 acc;
+        const float bj = bhs[l15];
 #pragma unroll
-            for (int j = 0; j < NDP_NHMAX; j += 4)
-                *reinterpret_cast<float4 *>(hr + j) = *reinterpret_cast<const float4 *>(o + j);
-            const float *pr = pe + t * 9;
-            *reinterpret_cast<float4 *>(hr + 16) = make_float4(pr[0], pr[1], pr[2], pr[3]);
-            *reinterpret_cast<float4 *>(hr + 20) = make_float4(pr[4], pr[5], 0.f, 0.f);
+        for (int r = 0; r < 4; ++r) acc[r] = bj;
+        const float *arow = bufA + (16 * wv + l15) * NDP_LD + 4 * lk;
+        const float *brow = whs + (l15 < NDP_WHROWS ? l15 : 0) * NDP_LD + 4 * lk;
+        const bool live = l15 < NDP_WHROWS;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const float4 a = *reinterpret_cast<const float4 *>(arow + 16 * q);
+            float4 b = *reinterpret_cast<const float4 *>(brow + 16 * q);
+            if (!live) b = make_float4(0.f, 0.f, 0.f, 0.f);
+            acc = MFMA16(a.x, b.x, acc);
+            acc = MFMA16(a.y, b.y, acc);
+            acc = MFMA16(a.z, b.z, acc);
+            acc = MFMA16(a.w, b.w, acc);
         }
-        if (p < io.n) {
-            PointHead c;
-            float out[3];
-            head_warp_fwd(hc, o, xs + 4 * t, c, out);
-            if (io.x_out) {
-                if (io.shift_out) { out[0] += io.shift_out[0]; out[1] += io.shift_out[1]; out[2] += io.shift_out[2]; }
-                io.x_out[3 * p] = out[0]; io.x_out[3 * p + 1] = out[1]; io.x_out[3 * p + 2] = out[2];
-            } else {
-                xs[4 * t] = out[0]; xs[4 * t + 1] = out[1]; xs[4 * t + 2] = out[2];
-            }
-            if (io.nonrig) io.nonrig[p] = c.nr;
-        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ho[(16 * wv + 4 * lk + r) * NDP_NHMAX + l15] = hc.mlp_scale * acc[r];
     }
+    PT(8);
     __syncthreads();
+    PT(9);
 }
 
+// warp (nets.py:119-129) of the tile's 64 points by ONE wave (lane = point): reads ho / xs / pe of the tile.
+__device__ __forceinline__ void fwd_warp(const HeadCfg &hc, const TileIO &io, int base, int lane, const float *ho,
+                                         const float *pe, float *xs) {
+    const int p = base + lane;
+    const float *o = ho + lane * NDP_NHMAX;
+    if (io.heads) {
+        float *hr = io.heads + (size_t)p * NDP_HROW;
+#pragma unroll
+        for (int j = 0; j < NDP_NHMAX; j += 4)
+            *reinterpret_cast<float4 *>(hr + j) = *reinterpret_cast<const float4 *>(o + j);
+        const float *pr = pe + lane * 9;
+        *reinterpret_cast<float4 *>(hr + 16) = make_float4(pr[0], pr[1], pr[2], pr[3]);
+        *reinterpret_cast<float4 *>(hr + 20) = make_float4(pr[4], pr[5], 0.f, 0.f);
+    }
+    if (p < io.n) {
+        PointHead c;
+        float out[3];
+        head_warp_fwd(hc, o, xs + 4 * lane, c, out);
+        if (io.x_out) {
+            if (io.shift_out) { out[0] += io.shift_out[0]; out[1] += io.shift_out[1]; out[2] += io.shift_out[2]; }
+            io.x_out[3 * (size_t)p] = out[0]; io.x_out[3 * (size_t)p + 1] = out[1]; io.x_out[3 * (size_t)p + 2] = out[2];
+        } else {
+            xs[4 * lane] = out[0]; xs[4 * lane + 1] = out[1]; xs[4 * lane + 2] = out[2];
+        }
+        if (io.nonrig) io.nonrig[p] = c.nr;
+    }
+}
+
+// All tiles of a workgroup through one level.  Software pipeline across tiles: while wave 0 warps tile i, waves
+// 1..3 (one per coordinate axis) encode tile i+1 into the other pe/xs set from an x value they fetched at the top
+// of tile i, so neither the x load latency nor sincosf sits on the critical path.
 __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob &job, float *sm) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     FwdWeights fw;
     fwd_load_weights(hc, job.params, sm, fw);
     TileIO io;
     io.x_in = job.x_in; io.shift_in = nullptr; io.x_out = job.x_out; io.shift_out = nullptr;
     io.act = job.act; io.heads = job.heads; io.nonrig = job.nonrig; io.n = job.n; io.plane = job.plane;
-    for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step)
-        fwd_tile(hc, fw, job.freq, io, tile * NDP_TILE, sm);
+    float *pe = sm + L_PE, *xs = sm + L_XS, *ho = sm + L_HO;
+    int tile = job.tile0, cur = 0;
+    if (tile >= job.n_tiles) return;
+    if (wv > 0) fwd_posenc(fwd_fetch_x(io, tile * NDP_TILE, lane, wv - 1), job.freq, lane, wv - 1, pe, xs, true);
+    __syncthreads();
+    for (; tile < job.n_tiles; tile += job.tile_step) {
+        const int next = tile + job.tile_step;
+        float xn = 0.f;
+        if (wv > 0 && next < job.n_tiles) xn = fwd_fetch_x(io, next * NDP_TILE, lane, wv - 1);
+        fwd_tile_core(hc, fw, io, tile * NDP_TILE, sm, pe + cur * (64 * 9));
+        if (wv == 0) fwd_warp(hc, io, tile * NDP_TILE, lane, ho, pe + cur * (64 * 9), xs + cur * (64 * 4));
+        else if (next < job.n_tiles)
+            fwd_posenc(xn, job.freq, lane, wv - 1, pe + (cur ^ 1) * (64 * 9), xs + (cur ^ 1) * (64 * 4), true);
+        __syncthreads();
+        cur ^= 1;
+    }
 }
 
 // Whole pyramid for one 64-point tile per workgroup: the points stay in LDS from level to level, the weights of
@@ -321,17 +403,25 @@ k_pyramid_fwd(ndp_layer_desc desc, int m, int k0, int p_stride, WarpJobs jobs) {
     const ndp_warp_job jb = jobs.j[blockIdx.y];
     const int base = blockIdx.x * NDP_TILE;
     if (base >= jb.n) return;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    float *pe = sm + L_PE, *xs = sm + L_XS, *ho = sm + L_HO;
     TileIO io;
     io.act = nullptr; io.heads = nullptr; io.nonrig = nullptr; io.n = jb.n; io.plane = 0;
+    io.x_in = jb.x; io.shift_in = jb.shift_in;
     for (int l = 0; l < m; ++l) {
         const HeadCfg hc = make_head_cfg(desc_at_level(desc, l));
         FwdWeights fw;
         fwd_load_weights(hc, jb.params + (size_t)l * p_stride, sm, fw);
-        io.x_in = l == 0 ? jb.x : nullptr;
-        io.shift_in = l == 0 ? jb.shift_in : nullptr;
         io.x_out = l == m - 1 ? jb.x_out : nullptr;
         io.shift_out = l == m - 1 ? jb.shift_out : nullptr;
-        fwd_tile(hc, fw, ldexpf(1.0f, l + 1 + k0), io, base, sm);
+        if (wv > 0) {
+            const float xa = l == 0 ? fwd_fetch_x(io, base, lane, wv - 1) : xs[4 * lane + wv - 1];
+            fwd_posenc(xa, ldexpf(1.0f, l + 1 + k0), lane, wv - 1, pe, xs, l == 0);
+        }
+        __syncthreads();
+        fwd_tile_core(hc, fw, io, base, sm, pe);
+        if (wv == 0) fwd_warp(hc, io, base, lane, ho, pe, xs);
+        __syncthreads();
     }
 }
 
@@ -351,7 +441,11 @@ enum : int {
     LB_PE = LB_DO + 64 * 17,              // [6][64]
     LB_TOTAL = LB_PE + 6 * 64
 };
-static constexpr int kSmemBwdBytes = LB_TOTAL * 4;       // 73.2 KB: two workgroups per CU
+#ifdef NDP_EXP_ONE_WG
+static constexpr int kSmemBwdBytes = 100 * 1024;         // experiment: force one workgroup per CU
+#else
+static constexpr int kSmemBwdBytes = LB_TOTAL * 4;
+#endif       // 73.2 KB: two workgroups per CU
 #define NDP_NHP 12                                        // head rows carried in registers (>= 11 used)
 
 struct BwdJob {
@@ -375,28 +469,36 @@ __device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] gl
     }
 }
 
-// dW[mt] += dz^T h   (rows o = 32*mt.., cols k = 32wv + l31), contraction over the tile's 64 points
+// dW += dz^T h over the tile's 64 points (the MFMA contraction index).  Accumulator block c holds the rows
+// o = 4*i + c (i = MFMA row 0..31): with that row permutation ONE ds_read_b128 of dz[p][4*l31 .. 4*l31+3] feeds the
+// A operands of all four blocks; the B operand is h[p][32wv + l31].  Operands of step ks+1 are fetched before the
+// MFMAs of step ks are issued (explicit software pipelining: the LDS latency used to be exposed every two MFMAs).
 __device__ __forceinline__ void tile_outer_128x32(const float *dz /*LDS [64][LD]*/, const float *hin /*LDS [64][LD]*/,
                                                   int wv, int l31, int h, f32x16 (&dW)[4]) {
-#pragma unroll 2
+    const float *ap = dz + (32 * h) * NDP_LD + 4 * l31;
+    const float *bp = hin + (32 * h) * NDP_LD + 32 * wv + l31;
+    float4 a = *reinterpret_cast<const float4 *>(ap);
+    float b = bp[0];
+#pragma unroll 4
     for (int ks = 0; ks < 32; ++ks) {
-        const int p = 32 * h + ks;
-        const float b = hin[p * NDP_LD + 32 * wv + l31];
-        const float *dr = dz + p * NDP_LD + l31;
-        const float a0 = dr[0], a1 = dr[32], a2 = dr[64], a3 = dr[96];
-        dW[0] = MFMA32(a0, b, dW[0]);
-        dW[1] = MFMA32(a1, b, dW[1]);
-        dW[2] = MFMA32(a2, b, dW[2]);
-        dW[3] = MFMA32(a3, b, dW[3]);
+        const int kn = ks < 31 ? ks + 1 : 31;
+        const float4 an = *reinterpret_cast<const float4 *>(ap + kn * NDP_LD);
+        const float bn = bp[kn * NDP_LD];
+        dW[0] = MFMA32(a.x, b, dW[0]);
+        dW[1] = MFMA32(a.y, b, dW[1]);
+        dW[2] = MFMA32(a.z, b, dW[2]);
+        dW[3] = MFMA32(a.w, b, dW[3]);
+        a = an;
+        b = bn;
     }
 }
 
 __device__ __forceinline__ void store_dW(float *g, const f32x16 (&dW)[4], int wv, int l31, int h) {
     const int col = 32 * wv + l31;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[(32 * m + mfma_row(r, h)) * NDP_W + col] = dW[m][r];
+        for (int r = 0; r < 16; ++r) g[(4 * mfma_row(r, h) + c) * NDP_W + col] = dW[c][r];
 }
 
 // head stage of the backward: dz2 = (dO Wh) * [h2 > 0] written over the h2 plane ; dWh += dO^T h2 ; dbh
@@ -463,6 +565,35 @@ __device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, 
 }
 static constexpr int kSmemBwdHBytes = (64 * NDP_LD + 64 * 17) * 4;      // 38 KB
 
+// load_tile_to_lds plus the column sums of the tile (a bias gradient), which fall out of the registers that carry
+// the copy: thread t adds its 8 rows of columns 4(t&31)..+3 to cs[]; the 8 row groups are folded once, at the end
+// of the kernel (a per-tile LDS read-and-add loop for the same sums used to cost 10k cycles per tile).
+__device__ __forceinline__ void load_tile_to_lds_colsum(const float *src, float *dst, float (&cs)[4]) {
+    const int t = threadIdx.x;
+    float4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const float4 *>(src)[t + 256 * i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int idx = t + 256 * i;
+        *reinterpret_cast<float4 *>(dst + (idx >> 5) * NDP_LD + 4 * (idx & 31)) = v[i];
+        cs[0] += v[i].x; cs[1] += v[i].y; cs[2] += v[i].z; cs[3] += v[i].w;
+    }
+}
+// fold the 8 row-group partials of load_tile_to_lds_colsum in group order -> out[128]   (sc: >= 1024 floats of LDS)
+__device__ __forceinline__ void colsum_finish(const float (&cs)[4], float *sc, float *out) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    *reinterpret_cast<float4 *>(sc + (t >> 5) * NDP_W + 4 * (t & 31)) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+    __syncthreads();
+    if (t < NDP_W) {
+        float s = sc[t];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) s += sc[g * NDP_W + t];
+        out[t] = s;
+    }
+}
+
 // hidden layer 2: dW2 += dz2^T h1 ; db2 ; dh1 = dz2 W2 ; dz1 = dh1 * [h1 > 0] written over dz2 (plane 2)
 __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
@@ -476,23 +607,29 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dW2[m][r] = 0.f;
-    const int o0 = t & 127, ph = t >> 7;
-    float gb2 = 0.f;
+    float gb2[4] = {0.f, 0.f, 0.f, 0.f};
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
         float *plane2 = job.act + (2 * (size_t)job.plane + base) * NDP_W;
-        load_tile_to_lds(plane2, bufB);                                            // dz2
+        PT_DECL;
+        load_tile_to_lds_colsum(plane2, bufB, gb2);                                // dz2 (+ db2)
         load_tile_to_lds(job.act + ((size_t)job.plane + base) * NDP_W, bufA);      // h1
+        PT(0);
         __syncthreads();
+        PT(1);
         {
             f32x16 d0, d1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
+#ifndef NDP_EXP_NO_OUTER
             tile_outer_128x32(bufB, bufA, wv, l31, h, dW2);
+#endif
+#ifndef NDP_EXP_NO_GEMM
             tile_gemm_64x32(bufB, w2t, l31, h, d0, d1);
-#pragma unroll 8
-            for (int pp = 0; pp < 32; ++pp) gb2 += bufB[(32 * ph + pp) * NDP_LD + o0];
+#endif
+            PT(2);
             __syncthreads();                       // every wave is done reading dz2
+            PT(3);
             // dz1 goes through LDS so that HBM sees coalesced float4 rows (and the epilogue needs one base
             // address instead of 32 per-element addresses, which used to cost 58 spilled registers)
             const int col = 32 * wv + l31;
@@ -503,20 +640,24 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
                 bufB[(row + 32) * NDP_LD + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? d1[r] : 0.f;
             }
         }
+        PT(4);
         __syncthreads();
+        PT(5);
         store_tile_from_lds(bufB, plane2);
+        PT(6);
         __syncthreads();
+        PT(7);
     }
     float *G = job.gpart;
     store_dW(G + ndp_off_Wi(&dd, 2), dW2, wv, l31, h);
-    float *sc = sm + LB_BUFA;
-    if (ph == 1) sc[o0] = gb2;
-    __syncthreads();
-    if (ph == 0) G[ndp_off_bi(&dd, 2) + o0] = gb2 + sc[o0];
+    colsum_finish(gb2, sm + LB_BUFA, G + ndp_off_bi(&dd, 2));
 }
 
+// hidden layer 1 and the input layer: dW1 += dz1^T h0 ; db1 ; dh0 = dz1 W1 ; dz0 = dh0 * [h0 > 0] ;
+// dW0 += dz0^T pe (16x16x4 MFMA: rows = the 6 posenc channels, columns = this wave's 32 outputs) ; db0
 __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int l15 = lane & 15, lk = lane >> 4;
     float *bufA = sm + LB_BUFA, *bufB = sm + LB_BUFB, *pe = sm + LB_PE;
     const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
     const float *W1 = job.params + ndp_off_Wi(&dd, 1);
@@ -527,13 +668,16 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dW1[m][r] = 0.f;
-    const int o0 = t & 127, ph = t >> 7;
-    float gW0[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float gb0 = 0.f, gb1 = 0.f;
+    f32x4 gW0a, gW0b;                              // dW0^T[c][o]: c = 4*lk + r, o = 32wv + l15 (a) / + 16 (b)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { gW0a[r] = 0.f; gW0b[r] = 0.f; }
+    float gb1[4] = {0.f, 0.f, 0.f, 0.f};
+    float gb0 = 0.f;                               // column 32wv + l31, the rows this lane holds in the MFMA C layout
 
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
-        // ---- dz1 tile -> bufB, h0 tile -> bufA, posenc -> pe
+        PT_DECL;
+        // ---- dz1 tile -> bufB (+ db1), h0 tile -> bufA, posenc -> pe
         {
             float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
             if (t < 64) {
@@ -541,67 +685,80 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
                 pa = *reinterpret_cast<const float4 *>(hr + 16);
                 pb = *reinterpret_cast<const float4 *>(hr + 20);
             }
-            load_tile_to_lds(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufB);
+            load_tile_to_lds_colsum(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufB, gb1);
             load_tile_to_lds(job.act + (size_t)base * NDP_W, bufA);
             if (t < 64) {
                 pe[t] = pa.x; pe[64 + t] = pa.y; pe[128 + t] = pa.z; pe[192 + t] = pa.w;
                 pe[256 + t] = pb.x; pe[320 + t] = pb.y;
             }
         }
+        PT(0);
         __syncthreads();
-        // ---- dW1 += dz1^T h0 ; dh0 = dz1 W1 ; db1
+        PT(1);
+        // ---- dW1 += dz1^T h0 ; dh0 = dz1 W1
         f32x16 d0, d1;
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
             tile_outer_128x32(bufB, bufA, wv, l31, h, dW1);
             tile_gemm_64x32(bufB, w1t, l31, h, d0, d1);
-#pragma unroll 8
-            for (int pp = 0; pp < 32; ++pp) gb1 += bufB[(32 * ph + pp) * NDP_LD + o0];
         }
+        PT(2);
         __syncthreads();
-        // ---- dz0 = dh0 * [h0 > 0] -> bufB
+        PT(3);
+        // ---- dz0 = dh0 * [h0 > 0] -> bufB ; db0 straight from the registers
         {
             const int col = 32 * wv + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, h);
-                bufB[row * NDP_LD + col] = bufA[row * NDP_LD + col] > 0.f ? d0[r] : 0.f;
-                bufB[(row + 32) * NDP_LD + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? d1[r] : 0.f;
+                const float z0 = bufA[row * NDP_LD + col] > 0.f ? d0[r] : 0.f;
+                const float z1 = bufA[(row + 32) * NDP_LD + col] > 0.f ? d1[r] : 0.f;
+                bufB[row * NDP_LD + col] = z0;
+                bufB[(row + 32) * NDP_LD + col] = z1;
+                gb0 += z0;
+                gb0 += z1;
             }
         }
+        PT(4);
         __syncthreads();
-        // ---- dW0 += dz0^T pe ; db0
+        PT(5);
+        // ---- dW0^T += pe^T dz0 on the 16x16x4 MFMA: A[c][p] = pe[c][p] (c < 6), B[p][o] = dz0[p][o]
         {
+            const float *ap = pe + (l15 < 6 ? l15 : 0) * 64 + lk;
+            const float *bp = bufB + lk * NDP_LD + 32 * wv + l15;
 #pragma unroll 4
-            for (int pp = 0; pp < 32; ++pp) {
-                const int p = 32 * ph + pp;
-                const float z = bufB[p * NDP_LD + o0];
-                gb0 += z;
-#pragma unroll
-                for (int c = 0; c < 6; ++c) gW0[c] = fmaf(z, pe[c * 64 + p], gW0[c]);
+            for (int ks = 0; ks < 16; ++ks) {
+                float a = ap[4 * ks];
+                if (l15 >= 6) a = 0.f;
+                const float b0 = bp[4 * ks * NDP_LD], b1 = bp[4 * ks * NDP_LD + 16];
+                gW0a = MFMA16(a, b0, gW0a);
+                gW0b = MFMA16(a, b1, gW0b);
             }
         }
+        PT(6);
         __syncthreads();
+        PT(7);
     }
     float *G = job.gpart;
     store_dW(G + ndp_off_Wi(&dd, 1), dW1, wv, l31, h);
-    float *sc = sm + LB_BUFA;
-    if (ph == 1) {
-        float *s = sc + o0 * 8;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) s[c] = gW0[c];
-        s[6] = gb0; s[7] = gb1;
-    }
-    __syncthreads();
-    if (ph == 0) {
-        const float *s = sc + o0 * 8;
+    {   // dW0[o][c]: lane holds c = 4*lk + r for its two columns
         float *gw0 = G + ndp_off_W0(&dd);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) gw0[o0 * 6 + c] = gW0[c] + s[c];
-        G[ndp_off_b0(&dd) + o0] = gb0 + s[6];
-        G[ndp_off_bi(&dd, 1) + o0] = gb1 + s[7];
+        for (int r = 0; r < 4; ++r) {
+            const int c = 4 * lk + r;
+            if (c < 6) {
+                gw0[(32 * wv + l15) * 6 + c] = gW0a[r];
+                gw0[(32 * wv + 16 + l15) * 6 + c] = gW0b[r];
+            }
+        }
     }
+    colsum_finish(gb1, sm + LB_BUFA, G + ndp_off_bi(&dd, 1));
+    __syncthreads();
+    float *sc = sm + LB_BUFA;
+    if (h == 1) sc[32 * wv + l31] = gb0;
+    __syncthreads();
+    if (h == 0) G[ndp_off_b0(&dd) + 32 * wv + l31] = gb0 + sc[32 * wv + l31];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -882,7 +1039,9 @@ k_eng_fwd(ndp_engine e, int parity) {
     job.plane = e.n_cap;
     job.tile0 = blockIdx.x;
     job.tile_step = gridDim.x;
+    PT_INIT;
     level_fwd_body(hc, job, sm);
+    PT_FLUSH(12);
 }
 
 // blockIdx.x < ceil(n_cap/512): source samples -> targets;  else targets -> source samples
@@ -1151,7 +1310,10 @@ k_eng_bwd2(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, false)) return;
+    PT_INIT;
+    desync_odd_slot(NDP_DESYNC);
     bwd2_body(make_head_cfg(desc_at_level(e.desc, 0)), job, sm);
+    PT_FLUSH(0);
 }
 
 extern "C" __global__ void __launch_bounds__(256, 2)
@@ -1159,7 +1321,10 @@ k_eng_bwd1(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, false)) return;
+    PT_INIT;
+    desync_odd_slot(NDP_DESYNC);
     bwd1_body(make_head_cfg(desc_at_level(e.desc, 0)), job, sm);
+    PT_FLUSH(24);
 }
 
 // fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state)
@@ -1322,6 +1487,17 @@ static int set_smem(const void *fn, int bytes) {
     for (auto &d : done) if (!d) { d = fn; break; }
     return 0;
 }
+
+#ifdef NDP_PHASE_TIMING
+extern "C" int ndp_debug_phase_read(unsigned long long *out64, int reset) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int ndp_version(void) { return 101; }
 extern "C" const char *ndp_last_error(void) { return g_err; }

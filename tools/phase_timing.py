@@ -1,0 +1,54 @@
+"""Per-phase shader-cycle breakdown of the level kernels (experiment build, -DNDP_PHASE_TIMING).
+
+    python tools/phase_timing.py [B] [ticks] [extra hipcc flags...]
+
+Builds a timing variant of the library next to the product one (never shipped), runs B pairs for `ticks`
+ticks at level 0 and prints, per phase, the cycles thread 0 of a workgroup spends per tile (mean over
+workgroups and tiles).  s_memtime ticks are shader cycles."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+extra = sys.argv[3:]
+lib = os.path.join(ROOT, "gpurun_out", "libndp_phase.so")
+os.makedirs(os.path.dirname(lib), exist_ok=True)
+src = os.path.join(ROOT, "deformationpyramid_amd", "csrc", "ndp_kernels.hip")
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                       "-DNDP_PHASE_TIMING"] + extra + ["-o", lib, src])
+os.environ["NDP_HIP_LIB"] = lib
+import torch
+from deformationpyramid_amd import _native as N
+from deformationpyramid_amd.config import load_config
+from deformationpyramid_amd.registration import Registration
+from deformationpyramid_amd.synthetic import synthetic_pair
+
+dev = torch.device("cuda:0")
+cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
+model = Registration(cfg)
+preps = [model._prepare(*[t.to(dev) for t in synthetic_pair(i)[:2]], None) for i in range(B)]
+eng = model._engine(B, preps[0])
+eng.load_jobs([p.load_job(b) for b, p in enumerate(preps)][:16])
+for i in range(16, B, 16):
+    eng.load_jobs([p.load_job(b) for b, p in enumerate(preps)][i:i + 16])
+eng.run_ticks(4)
+torch.cuda.synchronize()
+L = N.lib()
+buf = (ctypes.c_ulonglong * 64)()
+L.ndp_debug_phase_read(buf, 1)
+ms = eng.run_ticks_timed(ticks)
+L.ndp_debug_phase_read(buf, 1)
+tiles = B * (eng.n_cap // 64) * ticks
+names = {0: "bwd2 load+lds", 1: "bwd2 barrier", 2: "bwd2 mfma(outer+gemm)+db", 3: "bwd2 barrier", 4: "bwd2 epilogue",
+         5: "bwd2 barrier", 6: "bwd2 store", 7: "bwd2 barrier",
+         24: "bwd1 load+lds", 25: "bwd1 barrier", 26: "bwd1 mfma(outer+gemm)", 27: "bwd1 barrier", 28: "bwd1 dz0 epilogue+db0",
+         29: "bwd1 barrier", 30: "bwd1 dW0 (mfma16)", 31: "bwd1 barrier",
+         14: "fwd layer0", 15: "fwd barrier", 16: "fwd layer1+h0 store", 17: "fwd barrier", 18: "fwd layer2+h1 store",
+         19: "fwd barrier", 23: "fwd h2 store", 20: "fwd heads (mfma16)", 21: "fwd barrier"}
+print("per-tick ms [fwd nn loss bwdh bwd2 bwd1 upd]:", [round(x / ticks, 4) for x in ms])
+for grp, lo in (("bwd2", 0), ("fwd", 12), ("bwd1", 24)):
+    tot = sum(buf[i] for i in range(lo, lo + 12))
+    print(f"{grp}: {tot / tiles:.0f} cycles per tile (thread 0 wall)")
+    for i in range(lo, lo + 12):
+        if buf[i]:
+            print(f"   {names.get(i, i):28s} {buf[i] / tiles:9.0f}  {100.0 * buf[i] / tot:5.1f} %")
