@@ -58,22 +58,6 @@ __shared__ unsigned long long pt_acc[12];                 // per-workgroup accum
 #define PT(id)
 #endif
 
-// Two workgroups share a CU.  Launched together they fall into lock-step (both in their MFMA phase, then both
-// in their memory phase), which leaves the matrix pipe idle during the memory phases; the workgroup that got
-// the odd wave slot therefore starts half a tile period late (experiment: -DNDP_DESYNC=<sleeps of 8k cycles>).
-__device__ __forceinline__ void desync_odd_slot(int sleeps) {
-#ifdef NDP_DESYNC_BY_ID
-    const unsigned wave_slot = (blockIdx.y * gridDim.x + blockIdx.x) >= 256;
-#else
-    const unsigned wave_slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));   // HW_ID.wave_id
-#endif
-    if (wave_slot & 1)
-        for (int i = 0; i < sleeps; ++i) __builtin_amdgcn_s_sleep(127);
-}
-#ifndef NDP_DESYNC
-#define NDP_DESYNC 0
-#endif
-
 // ------------------------------------------------------------------------------------------------
 // LDS carve (floats).  All scratch lives in the dynamic region (16-byte aligned offsets).
 // ------------------------------------------------------------------------------------------------
@@ -441,11 +425,7 @@ enum : int {
     LB_PE = LB_DO + 64 * 17,              // [6][64]
     LB_TOTAL = LB_PE + 6 * 64
 };
-#ifdef NDP_EXP_ONE_WG
-static constexpr int kSmemBwdBytes = 100 * 1024;         // experiment: force one workgroup per CU
-#else
-static constexpr int kSmemBwdBytes = LB_TOTAL * 4;
-#endif       // 73.2 KB: two workgroups per CU
+static constexpr int kSmemBwdBytes = LB_TOTAL * 4;       // 73.2 KB: two workgroups per CU
 #define NDP_NHP 12                                        // head rows carried in registers (>= 11 used)
 
 struct BwdJob {
@@ -473,32 +453,30 @@ __device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] gl
 // o = 4*i + c (i = MFMA row 0..31): with that row permutation ONE ds_read_b128 of dz[p][4*l31 .. 4*l31+3] feeds the
 // A operands of all four blocks; the B operand is h[p][32wv + l31].  Operands of step ks+1 are fetched before the
 // MFMAs of step ks are issued (explicit software pipelining: the LDS latency used to be exposed every two MFMAs).
+// dW[mt] += dz^T h   (rows o = 32*mt.., cols k = 32wv + l31), contraction over the tile's 64 points.
+// (A variant with the dW rows permuted so that one ds_read_b128 feeds all four A operands, software-pipelined by
+//  hand, measured SLOWER: bwd1 0.214 ms against 0.180 ms -- the compiler's own schedule of the b32 reads wins.)
 __device__ __forceinline__ void tile_outer_128x32(const float *dz /*LDS [64][LD]*/, const float *hin /*LDS [64][LD]*/,
                                                   int wv, int l31, int h, f32x16 (&dW)[4]) {
-    const float *ap = dz + (32 * h) * NDP_LD + 4 * l31;
-    const float *bp = hin + (32 * h) * NDP_LD + 32 * wv + l31;
-    float4 a = *reinterpret_cast<const float4 *>(ap);
-    float b = bp[0];
-#pragma unroll 4
+#pragma unroll 2
     for (int ks = 0; ks < 32; ++ks) {
-        const int kn = ks < 31 ? ks + 1 : 31;
-        const float4 an = *reinterpret_cast<const float4 *>(ap + kn * NDP_LD);
-        const float bn = bp[kn * NDP_LD];
-        dW[0] = MFMA32(a.x, b, dW[0]);
-        dW[1] = MFMA32(a.y, b, dW[1]);
-        dW[2] = MFMA32(a.z, b, dW[2]);
-        dW[3] = MFMA32(a.w, b, dW[3]);
-        a = an;
-        b = bn;
+        const int p = 32 * h + ks;
+        const float b = hin[p * NDP_LD + 32 * wv + l31];
+        const float *dr = dz + p * NDP_LD + l31;
+        const float a0 = dr[0], a1 = dr[32], a2 = dr[64], a3 = dr[96];
+        dW[0] = MFMA32(a0, b, dW[0]);
+        dW[1] = MFMA32(a1, b, dW[1]);
+        dW[2] = MFMA32(a2, b, dW[2]);
+        dW[3] = MFMA32(a3, b, dW[3]);
     }
 }
 
 __device__ __forceinline__ void store_dW(float *g, const f32x16 (&dW)[4], int wv, int l31, int h) {
     const int col = 32 * wv + l31;
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) g[(4 * mfma_row(r, h) + c) * NDP_W + col] = dW[c][r];
+        for (int r = 0; r < 16; ++r) g[(32 * m + mfma_row(r, h)) * NDP_W + col] = dW[m][r];
 }
 
 // head stage of the backward: dz2 = (dO Wh) * [h2 > 0] written over the h2 plane ; dWh += dO^T h2 ; dbh
@@ -621,12 +599,8 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
             f32x16 d0, d1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
-#ifndef NDP_EXP_NO_OUTER
             tile_outer_128x32(bufB, bufA, wv, l31, h, dW2);
-#endif
-#ifndef NDP_EXP_NO_GEMM
             tile_gemm_64x32(bufB, w2t, l31, h, d0, d1);
-#endif
             PT(2);
             __syncthreads();                       // every wave is done reading dz2
             PT(3);
@@ -1311,7 +1285,6 @@ k_eng_bwd2(ndp_engine e, int parity) {
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, false)) return;
     PT_INIT;
-    desync_odd_slot(NDP_DESYNC);
     bwd2_body(make_head_cfg(desc_at_level(e.desc, 0)), job, sm);
     PT_FLUSH(0);
 }
@@ -1322,7 +1295,6 @@ k_eng_bwd1(ndp_engine e, int parity) {
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, false)) return;
     PT_INIT;
-    desync_odd_slot(NDP_DESYNC);
     bwd1_body(make_head_cfg(desc_at_level(e.desc, 0)), job, sm);
     PT_FLUSH(24);
 }
