@@ -4,6 +4,8 @@ same seeded inputs, and against the golden vectors captured from the reference.
 Bar (BASELINE.json north_star): integer/index results bit-exact; floating point within 1e-4 on
 warped coordinates -- tolerances are written at each assert.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -470,3 +472,49 @@ def test_engine_load_jobs_centres_samples_and_resets_the_slot(dev):
     bad = dict(jobs[0]); bad["S"] = 400
     with pytest.raises((ValueError, N.NdpError)):
         eng.load_jobs([bad])
+
+
+# ------------------------------------------------------------------------------ 1-NN: adversarial layouts
+def _nn_case(name):
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    u = lambda n, s=1.0: (torch.rand(n, 3, generator=g) - 0.5) * s
+    if name == "clusters":               # two tight blobs far apart: most cells empty, queries sit between them
+        y = torch.cat([u(900, 0.02) + 1.0, u(1100, 0.02) - 1.0])
+        x = torch.cat([u(500, 3.0), u(500, 0.02) + 1.0])
+    elif name == "far_queries":          # every query outside the references' bounding box, at all distances
+        y = u(2000)
+        x = u(1500) * torch.tensor([0.2, 0.2, 0.2]) + torch.tensor([5.0, -3.0, 40.0])
+    elif name == "plane":                # flat cloud: one grid axis collapses to a single cell
+        y = u(2000); y[:, 2] = 0.25
+        x = u(1800); x[:, 2] = x[:, 2] * 0.01
+    elif name == "line":                 # two axes collapse
+        y = u(1500); y[:, 1:] = 0.0
+        x = u(700)
+    elif name == "lattice_ties":         # integer lattice: massive exact ties in d2, lowest index must win
+        k = torch.arange(12, dtype=torch.float32)
+        y = torch.stack(torch.meshgrid(k, k, k, indexing="ij"), -1).reshape(-1, 3) * 0.125
+        y = y[torch.randperm(y.shape[0], generator=g)].contiguous()
+        x = (torch.stack(torch.meshgrid(k, k, k, indexing="ij"), -1).reshape(-1, 3)[:1500] + 0.5) * 0.125
+    elif name == "single_ref":
+        y = u(1); x = u(300)
+    elif name == "identical":            # every reference is the same point (zero extent)
+        y = torch.full((600, 3), 0.3); x = u(500)
+    elif name == "skewed":               # 95 % of the references in one corner cell
+        y = torch.cat([u(1900, 0.01) - 0.49, u(100)])
+        x = u(2000)
+    elif name == "large":
+        y = u(9000); x = u(700, 1.2)
+    return x.contiguous(), y.contiguous()
+
+
+@pytest.mark.parametrize("name", ["clusters", "far_queries", "plane", "line", "lattice_ties", "single_ref", "identical",
+                                  "skewed", "large"])
+def test_chamfer_nn_is_exact_on_adversarial_layouts(dev, name):
+    from deformationpyramid_amd import ops
+    x, y = _nn_case(name)
+    r = O().chamfer(x.numpy(), y.numpy(), want_grad=False, nthreads=8)
+    d2x, ix, d2y, iy = [t.cpu().numpy() for t in ops.chamfer_nn(x.to(dev), y.to(dev))]
+    np.testing.assert_array_equal(d2x, r["d2x"])
+    np.testing.assert_array_equal(d2y, r["d2y"])
+    np.testing.assert_array_equal(ix, r["idx_x"])
+    np.testing.assert_array_equal(iy, r["idx_y"])
