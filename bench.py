@@ -61,7 +61,7 @@ def kernel_profile(model, pairs, slots, n_ticks=24):
 
 def pmc_traffic(kernel, pairs):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled
-    per the gfx950 correction, WRITE_SIZE as is; collected by tools/pmc_traffic.sh at 64 pairs per launch and
+    per the gfx950 correction, WRITE_SIZE as is; collected by tools/pmc_traffic.sh at 128 pairs per launch and
     scaled linearly to this launch's pair count).  None when no such profile is committed."""
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
     try:
