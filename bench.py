@@ -118,6 +118,7 @@ def main():
     ap.add_argument("--slots", type=int, default=128, help="pairs resident per GPU (= pairs per step per GPU)")
     ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 16 x slots)")
     ap.add_argument("--chunk", type=int, default=4, help="ticks between host polls")
+    ap.add_argument("--engines", type=int, default=2, help="independent engines (HIP streams) per GPU, `slots` pairs each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -162,7 +163,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     def step():
-        return model.register_batch(pairs, slots=B, chunk=args.chunk)
+        return model.register_batch(pairs, slots=B, chunk=args.chunk, engines=args.engines)
 
     for _ in range(args.warmup):
         step()
@@ -208,7 +209,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": "synthetic 8192-pt pair, NDP.yaml (SE3/axis-angle, m=9, samples=2000, iters<=500, "
                                "early stop on), full register(): init + level/Adam loop + 8192-pt final warp",
-                   "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective"},
+                   "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B * args.engines, "engines_per_gpu": args.engines, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective"},
         "ms_per_iter": 1e3 * elapsed * n_gpus / max(n_steps, 1.0),
         "adam_iters_per_pair": n_steps / n_pairs,
         "loss_evals_per_pair": n_evals / n_pairs,

@@ -95,20 +95,23 @@ class Registration:
         return warped, iter_cnt, timer
 
     # ------------------------------------------------------------------ batched extension
-    def register_batch(self, pairs, slots=64, chunk=8, prefetch=True):
+    def register_batch(self, pairs, slots=64, chunk=8, prefetch=True, engines=1):
         """pairs: sequence of (src, tgt) or (src, tgt, (ldmk_s, ldmk_t)).  Pairs are prepared in order
         (so the CPU RNG stream is consumed exactly as by sequential register() calls) and optimised
-        `slots` at a time, finished slots being refilled.  With prefetch=True the host-side preparation
-        (RNG replay of the init, centring, sampling) runs in a producer thread ahead of the GPU.
+        `slots` at a time per engine, finished slots being refilled.  With prefetch=True the host-side preparation
+        (RNG replay of the init and of the sampling permutations) runs in a producer thread ahead of the GPU.
+        engines > 1 keeps that many independent engines ticking on their own HIP streams: their launches interleave on
+        the GPU, so the VALU-bound and latency-bound kernels of one overlap the MFMA-bound kernels of another.
         Returns [(warped, iter_cnt)] in input order."""
         pairs = list(pairs)
         if not pairs:
             return []
-        todo = queue.Queue(maxsize=max(2 * slots, 8))
+        engines = max(1, min(int(engines), len(pairs)))
+        todo = queue.Queue(maxsize=max(2 * slots * engines, 8))
         preps = [None] * len(pairs)
         dev = self._dev()
         side = torch.cuda.Stream(dev) if prefetch else None
-        fin_stream = torch.cuda.Stream(dev)                      # final all-point warps overlap the ticking engine
+        fin_stream = torch.cuda.Stream(dev)                      # final all-point warps overlap the ticking engines
 
         def produce():
             try:
@@ -137,7 +140,8 @@ class Registration:
             todo = queue.Queue()
             produce()
 
-        def next_prepared():
+        def next_prepared(stream):
+            """Next pair off the producer queue, made visible to `stream` (a lane's stream) and to fin_stream."""
             item = todo.get()
             if item is None:
                 return None
@@ -145,83 +149,109 @@ class Registration:
                 raise item
             i, p, ev = item
             if ev is not None:
-                cur = torch.cuda.current_stream(dev)
-                cur.wait_event(ev)
+                stream.wait_event(ev)
                 fin_stream.wait_event(ev)
                 for t in p.tensors():                # allocated on the producer's stream, consumed on these two
-                    t.record_stream(cur)
+                    t.record_stream(stream)
                     t.record_stream(fin_stream)
             else:
                 for t in p.tensors():
+                    t.record_stream(stream)
                     t.record_stream(fin_stream)
             preps[i] = p
             return i, p
 
-        first = next_prepared()
-        B = min(slots, len(pairs))
-        eng = self._engine(B, first[1], n_hint=self.config.samples + first[1].K)
-        eng.park_all()
-        # Pipelined control loop: the states of chunk k are read back while chunk k+1 runs, so the GPU
-        # never waits for the host; a slot that finishes in chunk k is refilled before chunk k+2.
-        # Refills of one round go up in ONE launch (k_eng_load), the final all-point warps of the pairs that
-        # finished in one chunk in ONE launch (k_pyramid_fwd) on a side stream.
-        fin_done = {}                                            # slot -> event: its parameters have been consumed
-        main = torch.cuda.current_stream(dev)
-        active, free, exhausted = {}, list(range(B)), False      # active: slot -> (pair index, first valid snapshot)
-        nxt = first
         m = self.config.m
-        seq = 0                                                  # snapshots taken so far
-        pending = None
-        while True:
-            jobs = []
-            while free and not exhausted:
-                if nxt is None:
-                    nxt = next_prepared()
+        main = torch.cuda.current_stream(dev)
+        shared = {"exhausted": False}
+
+        class Lane:
+            """One engine on one stream.  Pipelined control: the states of chunk k are read back while chunk k+1
+            runs, so the GPU never waits for the host; a slot that finishes in chunk k is refilled before chunk k+2.
+            Refills of one round go up in ONE launch (k_eng_load), the final all-point warps of the pairs that
+            finished in one chunk in ONE launch (k_pyramid_fwd) on the shared side stream."""
+
+            def __init__(lane, eng, stream):
+                lane.eng, lane.stream = eng, stream
+                lane.fin_done = {}                               # slot -> event: its parameters have been consumed
+                lane.active, lane.free = {}, list(range(eng.B))  # active: slot -> (pair index, first valid snapshot)
+                lane.seq, lane.pending, lane.done = 0, None, False
+
+            def step(lane, first=None):
+                eng = lane.eng
+                jobs = []
+                while lane.free and not shared["exhausted"]:
+                    nxt = first if first is not None else next_prepared(lane.stream)
+                    first = None
                     if nxt is None:
-                        exhausted = True
+                        shared["exhausted"] = True
                         break
-                i, p = nxt
-                nxt = None
-                slot = free.pop()
-                if slot in fin_done:
-                    main.wait_event(fin_done.pop(slot))          # the previous tenant's final warp read these params
-                jobs.append(p.load_job(slot))
-                active[slot] = (i, seq)                          # snapshots >= seq see this pair in the slot
-            if jobs:
-                eng.load_jobs(jobs)
-            if not active and pending is None:
-                break
-            handle = None
-            if active:
-                eng.run_ticks(chunk)
-                handle = (eng.snapshot_async(), seq)
-                seq += 1
-            if pending is not None:
-                (h, hseq) = pending
-                states = eng.wait_snapshot(h)
-                done = []
-                for slot in list(active):
-                    i, valid_from = active[slot]
-                    st = states[slot]
-                    if hseq < valid_from or st.level < m:
-                        continue
-                    del active[slot]
-                    preps[i].state = st
-                    done.append((slot, preps[i]))
-                    free.append(slot)
-                if done:
-                    # the snapshot proves every tick that touched these slots has completed: the final warp
-                    # needs no dependency on the main stream, only the slots' refill must wait for it
-                    with torch.cuda.stream(fin_stream):
-                        outs = self._finish(eng, done, freeze=True)
-                        ev = torch.cuda.Event()
-                        ev.record(fin_stream)
-                    for (slot, p), out in zip(done, outs):
-                        fin_done[slot] = ev
-                        out.record_stream(main)
-                        p.result = out
-                        p.release()
-            pending = handle
+                    i, p = nxt
+                    slot = lane.free.pop()
+                    if slot in lane.fin_done:
+                        lane.stream.wait_event(lane.fin_done.pop(slot))   # the previous tenant's final warp read these params
+                    jobs.append(p.load_job(slot))
+                    lane.active[slot] = (i, lane.seq)            # snapshots >= seq see this pair in the slot
+                if jobs:
+                    eng.load_jobs(jobs)
+                if not lane.active and lane.pending is None:
+                    lane.done = True
+                    return
+                handle = None
+                if lane.active:
+                    eng.run_ticks(chunk)
+                    handle = (eng.snapshot_async(), lane.seq)
+                    lane.seq += 1
+                if lane.pending is not None:
+                    (h, hseq) = lane.pending
+                    states = eng.wait_snapshot(h)
+                    done = []
+                    for slot in list(lane.active):
+                        i, valid_from = lane.active[slot]
+                        st = states[slot]
+                        if hseq < valid_from or st.level < m:
+                            continue
+                        del lane.active[slot]
+                        preps[i].state = st
+                        done.append((slot, preps[i]))
+                        lane.free.append(slot)
+                    if done:
+                        # the snapshot proves every tick that touched these slots has completed: the final warp
+                        # needs no dependency on the lane's stream, only the slots' refill must wait for it
+                        with torch.cuda.stream(fin_stream):
+                            outs = self._finish(eng, done, freeze=True)
+                            ev = torch.cuda.Event()
+                            ev.record(fin_stream)
+                        for (slot, p), out in zip(done, outs):
+                            lane.fin_done[slot] = ev
+                            out.record_stream(main)
+                            p.result = out
+                            p.release()
+                lane.pending = handle
+
+        first = next_prepared(main)
+        B = min(slots, -(-len(pairs) // engines))
+        lanes = []
+        for e in range(engines):
+            stream = main if engines == 1 else torch.cuda.Stream(dev)
+            eng = self._engine(B, first[1], n_hint=self.config.samples + first[1].K, lane=e)
+            with torch.cuda.stream(stream):
+                stream.wait_stream(main)
+                eng.park_all()
+            lanes.append(Lane(eng, stream))
+        if engines > 1:                                          # the first pair was made visible to `main` only
+            for t in first[1].tensors():
+                t.record_stream(lanes[0].stream)
+            lanes[0].stream.wait_stream(main)
+        while not all(lane.done for lane in lanes):
+            for lane in lanes:
+                if lane.done:
+                    continue
+                with torch.cuda.stream(lane.stream):
+                    lane.step(first)
+                first = None
+        for lane in lanes:
+            main.wait_stream(lane.stream)
         main.wait_stream(fin_stream)
         self.last_states = [p.state for p in preps]
         return [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
@@ -313,16 +343,18 @@ class Registration:
                 return host
         return torch.empty(numel, dtype=torch.float32).pin_memory()
 
-    def _engine(self, B, like, n_hint=0):
+    def _engine(self, B, like, n_hint=0, lane=0):
         n_cap = ops.cap(max(like.K + like.S, n_hint))
         t_cap = ops.cap(max(like.T, self.config.samples if like.S else 0))
         cfg = self._opt_config(like.K > 0)
         desc = like.desc
         key = (B, n_cap, t_cap, desc, tuple(sorted(vars(cfg).items())))
-        if key not in self._engines:
-            self._engines.clear()                      # one resident engine at a time
-            self._engines[key] = BatchedEngine(desc, cfg, B, n_cap, t_cap, self._dev())
-        return self._engines[key]
+        if self._engines.get("key") != key:
+            self._engines.clear()                      # one resident engine configuration at a time
+            self._engines["key"] = key
+        if lane not in self._engines:
+            self._engines[lane] = BatchedEngine(desc, cfg, B, n_cap, t_cap, self._dev())
+        return self._engines[lane]
 
     def _finish(self, eng, done, freeze=False):
         """registration.py:253-262 for every (slot, prepared pair) of `done`, in one launch: ALL source points through

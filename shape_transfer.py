@@ -53,7 +53,7 @@ if __name__ == "__main__":
     dev = torch.device("cuda", config.device)
     src_mean = torch.from_numpy(src_pcd).to(dev).mean(dim=0, keepdim=True)
     verts = torch.from_numpy(src_v).to(dev) - src_mean
-    eng = next(iter(model._engines.values()))
+    eng = model._engines[0]
     warped_vert = ops.pyramid_fwd(eng.desc, config.m, config.k0, eng.params[0], verts.contiguous()).cpu().numpy()
     print("warped", warped_vert.shape[0], "vertices; bbox", warped_vert.min(0), warped_vert.max(0))
     if args.o:

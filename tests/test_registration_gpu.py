@@ -123,6 +123,10 @@ def test_register_batch_equals_sequential_register(cfg):
     for (wa, ca), (wb, cb) in zip(a, b):
         assert torch.equal(wa, wb) and ca == cb
     torch.manual_seed(3)
+    e2 = Registration(c).register_batch(pairs, slots=2, engines=2, chunk=3)     # two engines on two streams, same G
+    for (wa, ca), (wb, cb) in zip(a, e2):
+        assert torch.equal(wa, wb) and ca == cb
+    torch.manual_seed(3)
     model = Registration(c)
     for (src, tgt), (wa, ca) in zip(pairs, a):
         model.load_pcds(src, tgt)
