@@ -518,3 +518,25 @@ def test_chamfer_nn_is_exact_on_adversarial_layouts(dev, name):
     np.testing.assert_array_equal(d2y, r["d2y"])
     np.testing.assert_array_equal(ix, r["idx_x"])
     np.testing.assert_array_equal(iy, r["idx_y"])
+
+
+def test_config3_stress_samples_8192(dev):
+    """BASELINE config 3 (samples = 8192, Chamfer-bound): S = T = 8192 in the engine, two slots of different sizes."""
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=8192, T=8192, m=2, iters=2, early_stop=False,
+                                          w_cd=1.0, trunc=1e9, B=2)
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.level == 2 and st.total_steps == 4
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+        assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+
+
+def test_config2_fixed_work_450_iterations_per_pair(dev):
+    """early stop off, 50 iterations x 9 levels = exactly 450 Adam steps per pair; the
+    loss trace of the whole run stays within the per-step budget of the oracle's (small clouds keep the oracle fast)."""
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=256, T=240, m=9, iters=50, early_stop=False,
+                                          w_cd=1.0, trunc=1e9, B=2)
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.level == 9 and st.total_steps == 450 and st.total_evals == 450
+        assert list(st.evals_per_level[:9]) == [50] * 9
+        # 450 chaotic steps: the end point agrees at the trajectory-noise level, the loss within a few percent
+        assert abs(st.loss - ref["loss_trace"][-1]) < 0.05 * abs(ref["loss_trace"][-1])
