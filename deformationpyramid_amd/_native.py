@@ -114,6 +114,8 @@ _SIGS = {
     "ndp_pyramid_fwd": [DP, I, I, V, I, V, I, V, V, V],
     "ndp_pyramid_fwd_batch": [DP, I, I, I, ctypes.POINTER(WarpJob), I, V],
     "ndp_pair_means": [V, I, V, I, V, V],
+    "ndp_nsfp_fwd": [V, V, I, V, V, V, V],
+    "ndp_nsfp_bwd": [V, V, I, V, V, V, V, I, I, V],
     "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],
     "ndp_chamfer_l1_bwd": [V, I, V, I, F, V, V, V, V, V, V, V],
     "ndp_landmark_mse_fwd_bwd": [V, V, I, V, V, V],

@@ -435,7 +435,21 @@ struct BwdJob {
     const float *dO;        // [plane][16]
     float *gpart;           // this workgroup's partial [P]
     int n, plane, n_tiles, tile0, tile_step;
+    // layer-generic view used by bwdh / bwd2 (the NDP callers derive it from `act`; the NSFP chain walks its 8 planes):
+    float *dz_plane;        // [plane][128] gradient wrt the layer's pre-activation, rewritten in place for the layer below
+    const float *h_plane;   // [plane][128] the layer's input activation (post-ReLU)
+    int w_off, b_off;       // offsets of the layer's weight / bias inside params and inside the partial
 };
+
+// NDP level: which slice of the flat parameter block the two generic backward stages work on
+__host__ __device__ inline void bwd_job_ndp_heads(BwdJob &job) {
+    const ndp_layer_desc dd = {NDP_W, 2, 0, 0, 0, 0.f};
+    job.w_off = ndp_off_Wi(&dd, 3); job.b_off = 0;
+}
+__host__ __device__ inline void bwd_job_ndp_layer2(BwdJob &job) {
+    const ndp_layer_desc dd = {NDP_W, 2, 0, 0, 0, 0.f};
+    job.w_off = ndp_off_Wi(&dd, 2); job.b_off = ndp_off_bi(&dd, 2);
+}
 
 __device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] global*/, float *dst /*LDS [64][LD]*/) {
     const int t = threadIdx.x;
@@ -485,7 +499,7 @@ __device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
     float *bufA = sm, *dOs = sm + 64 * NDP_LD;
     const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
-    const float *Wh = job.params + ndp_off_Wi(&dd, 3);
+    const float *Wh = job.params + job.w_off;
     // head matrix as an MFMA B operand: whb[ks] = Wh[j = 2ks + h][k = 32wv + l31], K = 16 head slots
     float whb[8];
 #pragma unroll
@@ -496,7 +510,7 @@ __device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, 
     float gbh = 0.f;
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
-        float *plane2 = job.act + (2 * (size_t)job.plane + base) * NDP_W;
+        float *plane2 = job.dz_plane + (size_t)base * NDP_W;
         {
             const float4 dv = reinterpret_cast<const float4 *>(job.dO + (size_t)base * NDP_NHMAX)[t];
             load_tile_to_lds(plane2, bufA);
@@ -533,7 +547,7 @@ __device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, 
         }
         __syncthreads();
     }
-    float *gwh = job.gpart + ndp_off_Wi(&dd, 3);
+    float *gwh = job.gpart + job.w_off;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int j = mfma_row(r, h);
@@ -577,7 +591,7 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
     float *bufA = sm + LB_BUFA, *bufB = sm + LB_BUFB;
     const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
-    const float *W2 = job.params + ndp_off_Wi(&dd, 2);
+    const float *W2 = job.params + job.w_off;
     float w2t[64];
     load_w_bwd(W2, wv, l31, h, w2t);
     f32x16 dW2[4];
@@ -588,10 +602,10 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
     float gb2[4] = {0.f, 0.f, 0.f, 0.f};
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
-        float *plane2 = job.act + (2 * (size_t)job.plane + base) * NDP_W;
+        float *plane2 = job.dz_plane + (size_t)base * NDP_W;
         PT_DECL;
         load_tile_to_lds_colsum(plane2, bufB, gb2);                                // dz2 (+ db2)
-        load_tile_to_lds(job.act + ((size_t)job.plane + base) * NDP_W, bufA);      // h1
+        load_tile_to_lds(job.h_plane + (size_t)base * NDP_W, bufA);                // h1
         PT(0);
         __syncthreads();
         PT(1);
@@ -623,8 +637,8 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
         PT(7);
     }
     float *G = job.gpart;
-    store_dW(G + ndp_off_Wi(&dd, 2), dW2, wv, l31, h);
-    colsum_finish(gb2, sm + LB_BUFA, G + ndp_off_bi(&dd, 2));
+    store_dW(G + job.w_off, dW2, wv, l31, h);
+    colsum_finish(gb2, sm + LB_BUFA, G + job.b_off);
 }
 
 // hidden layer 1 and the input layer: dW1 += dz1^T h0 ; db1 ; dh0 = dz1 W1 ; dz0 = dh0 * [h0 > 0] ;
@@ -1268,6 +1282,8 @@ __device__ __forceinline__ bool eng_bwd_job(const ndp_engine &e, int parity, Bwd
     job.gpart = gpart;
     job.n = n; job.plane = e.n_cap; job.n_tiles = n_tiles;
     job.tile0 = blockIdx.x; job.tile_step = gridDim.x;
+    job.dz_plane = job.act + 2 * (size_t)e.n_cap * NDP_W;
+    job.h_plane = job.act + (size_t)e.n_cap * NDP_W;
     return true;
 }
 
@@ -1276,6 +1292,7 @@ k_eng_bwdh(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, true)) return;
+    bwd_job_ndp_heads(job);
     bwdh_body(make_head_cfg(desc_at_level(e.desc, e.state[(size_t)(parity ^ 1) * e.B + blockIdx.y].step_level)), job, sm);
 }
 
@@ -1284,6 +1301,7 @@ k_eng_bwd2(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, false)) return;
+    bwd_job_ndp_layer2(job);
     PT_INIT;
     bwd2_body(make_head_cfg(desc_at_level(e.desc, 0)), job, sm);
     PT_FLUSH(0);
@@ -1324,6 +1342,139 @@ k_eng_update(ndp_engine e, int parity) {
         p[i] = pi; m[i] = mi; v[i] = vi;
     }
     if (ns.decision != NDP_DEC_STEP) { m[i] = 0.f; v[i] = 0.f; }             // registration.py:176
+}
+
+// ------------------------------------------------------------------------------------------------
+// Neural scene-flow prior baseline (nets.py:256-292): one launch per layer
+// ------------------------------------------------------------------------------------------------
+// h1 = relu(W1 x + b1): thread -> (row, 4 consecutive outputs), coalesced float4 rows; zero rows beyond n
+extern "C" __global__ void __launch_bounds__(256)
+k_nsfp_in(const float *params, const float *x, int n, float *h1 /*[plane][128]*/, int plane) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;           // float4 index
+    const int p = idx >> 5, o = 4 * (idx & 31);
+    if (p >= plane) return;
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p < n) {
+        const float *W = params + ndp_nsfp_off_W(1), *b = params + ndp_nsfp_off_b(1);
+        const float x0 = x[3 * (size_t)p], x1 = x[3 * (size_t)p + 1], x2 = x[3 * (size_t)p + 2];
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float *w = W + 3 * (o + c);
+            const float z = fmaf(w[2], x2, fmaf(w[1], x1, fmaf(w[0], x0, b[o + c])));
+            v[c] = z > 0.f ? z : 0.f;
+        }
+        r = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    reinterpret_cast<float4 *>(h1)[idx] = r;
+}
+
+// y = relu(W h + b), 128 -> 128, tiles of 64 points; wave w owns output columns [32w, 32w+32), weight slice stationary
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_nsfp_dense(const float *W, const float *b, const float *hin, float *hout, int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *bufA = sm, *bufB = sm + 64 * NDP_LD;
+    float w[64];
+    load_w_fwd(W, wv, l31, h, w);
+    const float bias = b[32 * wv + l31];
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        load_tile_to_lds(hin + (size_t)tile * NDP_TILE * NDP_W, bufA);
+        __syncthreads();
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc0[r] = bias; acc1[r] = bias; }
+        tile_gemm_64x32(bufA, w, l31, h, acc0, acc1);
+        const int col = 32 * wv + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = mfma_row(r, h);
+            bufB[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
+            bufB[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
+        }
+        __syncthreads();
+        store_tile_from_lds(bufB, hout + (size_t)tile * NDP_TILE * NDP_W);
+        __syncthreads();
+    }
+}
+
+// x_out = x + W9 h8 + b9: thread (point = t & 63, coordinate = t >> 6 < 3), four independent fmaf chains
+extern "C" __global__ void __launch_bounds__(256)
+k_nsfp_out(const float *params, const float *h8, const float *x, int n, float *x_out) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * NDP_LD];
+    __shared__ __attribute__((aligned(16))) float w9[3 * NDP_W];
+    const int t = threadIdx.x, base = blockIdx.x * NDP_TILE;
+    load_tile_to_lds(h8 + (size_t)base * NDP_W, tile);
+    for (int i = t; i < 3 * NDP_W; i += 256) w9[i] = params[ndp_nsfp_off_W(NDP_NSFP_LAYERS) + i];
+    __syncthreads();
+    const int p = base + (t & 63), j = t >> 6;
+    if (j < 3 && p < n) {
+        const float *hr = tile + (t & 63) * NDP_LD, *wr = w9 + j * NDP_W;
+        float a0 = params[ndp_nsfp_off_b(NDP_NSFP_LAYERS) + j], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+        for (int k4 = 0; k4 < 32; ++k4) {
+            const float4 hv = *reinterpret_cast<const float4 *>(hr + 4 * k4);
+            const float4 wv4 = *reinterpret_cast<const float4 *>(wr + 4 * k4);
+            a0 = fmaf(wv4.x, hv.x, a0); a1 = fmaf(wv4.y, hv.y, a1);
+            a2 = fmaf(wv4.z, hv.z, a2); a3 = fmaf(wv4.w, hv.w, a3);
+        }
+        x_out[3 * (size_t)p + j] = x[3 * (size_t)p + j] + ((a0 + a1) + (a2 + a3));
+    }
+}
+
+// dO[p][0..2] = g[p], zero elsewhere (rows up to plane): the output layer then runs through the head-stage kernel
+extern "C" __global__ void __launch_bounds__(256)
+k_nsfp_pack_g(const float *g, int n, int plane, float *dO) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= plane) return;
+    float4 *o = reinterpret_cast<float4 *>(dO + (size_t)p * NDP_NHMAX);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    o[0] = p < n ? make_float4(g[3 * (size_t)p], g[3 * (size_t)p + 1], g[3 * (size_t)p + 2], 0.f) : z;
+    o[1] = z; o[2] = z; o[3] = z;
+}
+
+// dW1[o][c] += sum_p dz1[p][o] x[p][c] ; db1[o] += sum_p dz1[p][o]: thread holds 8 rows x 4 columns of every tile
+extern "C" __global__ void __launch_bounds__(256)
+k_nsfp_in_bwd(const float *dz1 /*[plane][128]*/, const float *x, int n, int n_tiles, float *gpart, int p_stride) {
+    __shared__ __attribute__((aligned(16))) float sc[8][NDP_W * 4];
+    const int t = threadIdx.x, rg = t >> 5, o = 4 * (t & 31);
+    float aw[4][3], ab[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { ab[c] = 0.f; aw[c][0] = aw[c][1] = aw[c][2] = 0.f; }
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int base = tile * NDP_TILE;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int p = base + rg + 8 * i;
+            const float4 z = *reinterpret_cast<const float4 *>(dz1 + (size_t)p * NDP_W + o);
+            float xv[3] = {0.f, 0.f, 0.f};
+            if (p < n) { xv[0] = x[3 * (size_t)p]; xv[1] = x[3 * (size_t)p + 1]; xv[2] = x[3 * (size_t)p + 2]; }
+            const float zz[4] = {z.x, z.y, z.z, z.w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                ab[c] += zz[c];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) aw[c][a] = fmaf(zz[c], xv[a], aw[c][a]);
+            }
+        }
+    }
+    // fold the 8 row groups in group order
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float *s = &sc[rg][4 * (o + c)];
+        s[0] = aw[c][0]; s[1] = aw[c][1]; s[2] = aw[c][2]; s[3] = ab[c];
+    }
+    __syncthreads();
+    if (t < NDP_W) {
+        float r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) r[a] += sc[g8][4 * t + a];
+        float *G = gpart + (size_t)blockIdx.x * p_stride;
+        G[ndp_nsfp_off_W(1) + 3 * t] = r[0]; G[ndp_nsfp_off_W(1) + 3 * t + 1] = r[1]; G[ndp_nsfp_off_W(1) + 3 * t + 2] = r[2];
+        G[ndp_nsfp_off_b(1) + t] = r[3];
+    }
 }
 
 // ---- pair preparation (registration.py:150-164) and slot (re)fill, batched over pairs ----------------------
@@ -1524,7 +1675,11 @@ extern "C" int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, in
     const HeadCfg hc = make_head_cfg(*desc);
     hipLaunchKernelGGL(k_head_bwd, dim3((job.plane + 255) / 256), dim3(256), 0, s, hc, x, heads, g,
                        desc->nonrigidity ? g_nr : nullptr, n, job.plane, dO_work);
+    job.dz_plane = act + 2 * (size_t)job.plane * NDP_W;
+    job.h_plane = act + (size_t)job.plane * NDP_W;
+    bwd_job_ndp_heads(job);
     hipLaunchKernelGGL(k_level_bwdh, dim3(n_part), dim3(256), kSmemBwdHBytes, s, hc, job, p_stride);
+    bwd_job_ndp_layer2(job);
     hipLaunchKernelGGL(k_level_bwd2, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
     hipLaunchKernelGGL(k_level_bwd1, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
     HIP_TRY(hipGetLastError(), "level backward launch");
@@ -1628,6 +1783,71 @@ extern "C" int ndp_engine_load(const ndp_engine *e, int tick, const ndp_load_job
     }
     hipLaunchKernelGGL(k_eng_load, dim3(32, n_jobs), dim3(256), 0, (hipStream_t)stream, *e, tick & 1, lj);
     HIP_TRY(hipGetLastError(), "k_eng_load launch");
+    return 0;
+}
+
+static constexpr int kSmemDenseBytes = 2 * 64 * NDP_LD * 4;
+
+extern "C" int ndp_nsfp_fwd(const float *params, const float *x, int n, float *x_out, float *act, float *tmp, void *stream) {
+    if (n < 0 || !params || (n > 0 && (!x || !x_out)) || (n > 0 && !act && !tmp))
+        return fail(NDP_E_INVALID, "ndp_nsfp_fwd: null pointer / negative n");
+    if (!aligned16(params) || (act && !aligned16(act)) || (tmp && !aligned16(tmp)))
+        return fail(NDP_E_INVALID, "ndp_nsfp_fwd: params/act/tmp must be 16-byte aligned");
+    if (n == 0) return 0;
+    if (int rc = set_smem((const void *)k_nsfp_dense, kSmemDenseBytes)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int n_tiles = (n + NDP_TILE - 1) / NDP_TILE, plane = n_tiles * NDP_TILE;
+    const size_t psz = (size_t)plane * NDP_W;
+    float *cur = act ? act : tmp;
+    hipLaunchKernelGGL(k_nsfp_in, dim3((plane * 32 + 255) / 256), dim3(256), 0, s, params, x, n, cur, plane);
+    const int grid = n_tiles < 512 ? n_tiles : 512;
+    for (int l = 2; l <= NDP_NSFP_LAYERS - 1; ++l) {
+        float *nxt = act ? act + (size_t)(l - 1) * psz : (cur == tmp ? tmp + psz : tmp);
+        hipLaunchKernelGGL(k_nsfp_dense, dim3(grid), dim3(256), kSmemDenseBytes, s, params + ndp_nsfp_off_W(l),
+                           params + ndp_nsfp_off_b(l), cur, nxt, n_tiles);
+        cur = nxt;
+    }
+    hipLaunchKernelGGL(k_nsfp_out, dim3(n_tiles), dim3(256), 0, s, params, cur, x, n, x_out);
+    HIP_TRY(hipGetLastError(), "nsfp forward launch");
+    return 0;
+}
+
+extern "C" int ndp_nsfp_bwd(const float *params, const float *x, int n, float *act, const float *g,
+                            float *dO_work, float *grads_part, int n_part, int p_stride, void *stream) {
+    if (n <= 0 || !params || !x || !act || !g || !dO_work || !grads_part || n_part < 1)
+        return fail(NDP_E_INVALID, "ndp_nsfp_bwd: null pointer / bad sizes");
+    if (p_stride < ndp_nsfp_param_count()) return fail(NDP_E_INVALID, "ndp_nsfp_bwd: p_stride < P");
+    if (!aligned16(params) || !aligned16(act) || !aligned16(dO_work))
+        return fail(NDP_E_INVALID, "ndp_nsfp_bwd: params/act/dO_work must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    BwdJob job;
+    memset(&job, 0, sizeof job);
+    job.params = params; job.dO = dO_work; job.gpart = grads_part;
+    job.n = n; job.n_tiles = (n + NDP_TILE - 1) / NDP_TILE; job.plane = job.n_tiles * NDP_TILE;
+    const size_t psz = (size_t)job.plane * NDP_W;
+    if (n_part > job.n_tiles) {                                  // partials with no tile must read as zero
+        HIP_TRY(hipMemsetAsync(grads_part + (size_t)job.n_tiles * p_stride, 0,
+                               sizeof(float) * (size_t)(n_part - job.n_tiles) * p_stride, s), "memset");
+        n_part = job.n_tiles;
+    }
+    if (int rc = set_smem((const void *)k_level_bwd2, kSmemBwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_level_bwdh, kSmemBwdHBytes)) return rc;
+    // output layer = a 3-row head stage: dz8 = (g W9) * [h8 > 0] over plane 7 ; dW9 += g^T h8 ; db9
+    ndp_layer_desc d3 = {NDP_W, 2, NDP_MOTION_SFLOW, NDP_ROT_AXIS_ANGLE, 0, 1.0f};
+    const HeadCfg hc = make_head_cfg(d3);                        // nh = 3
+    hipLaunchKernelGGL(k_nsfp_pack_g, dim3((job.plane + 255) / 256), dim3(256), 0, s, g, n, job.plane, dO_work);
+    float *dz = act + 7 * psz;
+    job.dz_plane = dz; job.h_plane = nullptr;
+    job.w_off = ndp_nsfp_off_W(NDP_NSFP_LAYERS); job.b_off = 0;
+    hipLaunchKernelGGL(k_level_bwdh, dim3(n_part), dim3(256), kSmemBwdHBytes, s, hc, job, p_stride);
+    // hidden layers 8..2: dW_l += dz_l^T h_{l-1} ; db_l ; dz_{l-1} = (dz_l W_l) * [h_{l-1} > 0], in place in `dz`
+    for (int l = NDP_NSFP_LAYERS - 1; l >= 2; --l) {
+        job.h_plane = act + (size_t)(l - 2) * psz;
+        job.w_off = ndp_nsfp_off_W(l); job.b_off = ndp_nsfp_off_b(l);
+        hipLaunchKernelGGL(k_level_bwd2, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
+    }
+    hipLaunchKernelGGL(k_nsfp_in_bwd, dim3(n_part), dim3(256), 0, s, dz, x, n, job.n_tiles, grads_part, p_stride);
+    HIP_TRY(hipGetLastError(), "nsfp backward launch");
     return 0;
 }
 

@@ -74,7 +74,11 @@ class Registration:
     def register(self, **kwargs):
         if self.deformation_model == "NDP":
             return self.optimize_deformation_pyramid(**kwargs)
-        # Sinkhorn / ED / NSFP / Nerfies are comparison baselines outside this path
+        if self.deformation_model == "NSFP":                      # registration.py:112-113 -> (warped, None)
+            from .nsfp import optimize_neural_SFlow
+            kwargs.pop("timer", None)
+            return optimize_neural_SFlow(self, **kwargs)
+        # Sinkhorn / ED / Nerfies are comparison baselines outside this path
         raise KeyError(self.deformation_model)
 
     def optimize_deformation_pyramid(self, visualize=False, timer=None):

@@ -13,7 +13,8 @@ then `compute_flow_metrics` averaged by `AverageMeter`, then the timer report.  
   (the 14 GB download is not available offline) `--synthetic N` seeded pairs stand in (SURVEY.md section 8d);
 * `--batched` registers all pairs through `Registration.register_batch` (many pairs resident on the
   GPU); without it the loop calls `register()` pair by pair exactly like upstream;
-* only `deformation_model: NDP` is served (the other models are comparison baselines).
+* `deformation_model: NDP` and the `NSFP` baseline (config/baselines/NSFP.yaml) are served; the other models are
+  comparison baselines outside the scope.
 """
 import argparse
 import glob
@@ -82,7 +83,7 @@ def main():
     args = ap.parse_args()
     setup_seed(0)                                                           # once per process, as upstream
     config = load_config(args.config, make_dirs=True)
-    if config.deformation_model != "NDP":
+    if config.deformation_model not in ("NDP", "NSFP"):
         raise KeyError(config.deformation_model)
     model = Registration(config)
     timer = Timers()
@@ -96,7 +97,16 @@ def main():
             data = SyntheticPairs(args.synthetic)
         logger = Logger(os.path.join(config.snapshot_dir, benchmark + ".log"))
         items = [data[i] for i in range(len(data))]
-        if args.batched:
+        if config.deformation_model == "NSFP":                              # eval_nolearned.py:97-110
+            flows = []
+            for src, tgt, _, _ in items:
+                model.load_pcds(src, tgt)
+                timer.tic("registration")
+                warped, smpl_ind = model.register(visualize=args.visualize)
+                torch.cuda.synchronize()
+                timer.toc("registration")
+                flows.append((warped - model.src_pcd).cpu())
+        elif args.batched:
             timer.tic("registration")
             results = model.register_batch([(s, t) for s, t, _, _ in items], slots=args.slots)
             torch.cuda.synchronize()

@@ -87,6 +87,19 @@ int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_strid
  * means[4..6] = target (means[3], means[7] = 0).  Accumulated in double in a fixed order, rounded once.   */
 int ndp_pair_means(const float *src, int n_src, const float *tgt, int n_tgt, float *means, void *stream);
 
+/* ---- Neural scene-flow prior (NSFP) baseline, SURVEY section 8 f3 ----------------------------------------------
+ * x_out = x + MLP(x) with the 9-layer ReLU MLP of nets.py:256-292 (parameter layout: ndp_types.h), one launch per
+ * layer, the 128x128 layers on the fp32 MFMA with the weight slice stationary in registers.
+ * act: [8][cap][128] post-ReLU activations h1..h8 (cap = n rounded up to 64) saved for ndp_nsfp_bwd, or NULL for
+ * inference, in which case tmp [2][cap][128] is the ping-pong scratch.  (registration.py:506-507, :534-536)          */
+int ndp_nsfp_fwd(const float *params, const float *x, int n, float *x_out, float *act, float *tmp, void *stream);
+
+/* Gradient of a scalar loss wrt all parameters given g = dL/dx_out [n][3] (autograd of registration.py:506-529).
+ * act is consumed (h8 is overwritten by the running dz).  dO_work [cap][16]; grads_part [n_part][p_stride]
+ * partials, one per workgroup, to be folded by ndp_grad_reduce (deterministic order, no atomics).                 */
+int ndp_nsfp_bwd(const float *params, const float *x, int n, float *act, const float *g,
+                 float *dO_work, float *grads_part, int n_part, int p_stride, void *stream);
+
 /* Exact brute-force 1-NN in both directions (pytorch3d knn_points K=1 as called at loss.py:177-178):
  * d2x[i] = min_j |x_i - y_j|^2 (fma chain over x,y,z), idx_x[i] = lowest argmin; same for y->x.  */
 int ndp_chamfer_nn_fwd(const float *x, int S, const float *y, int T,

@@ -66,6 +66,20 @@ NDP_HD static inline int ndp_off_Wh(const ndp_layer_desc *d) { return ndp_off_Wi
 NDP_HD static inline int ndp_off_bh(const ndp_layer_desc *d) { return ndp_off_Wh(d) + ndp_n_heads(d) * d->width; }
 NDP_HD static inline int ndp_param_count(const ndp_layer_desc *d) { return ndp_off_bh(d) + ndp_n_heads(d); }
 
+/* ---- Neural scene-flow prior baseline (/root/reference/model/nets.py:256-292) ----------------
+ * flow(x) = L9(relu(L8(... relu(L1(x)) ...))), L1: 3 -> 128, L2..L8: 128 -> 128, L9: 128 -> 3.  Flat layout, layers in
+ * construction order, weight (row-major [out][in]) then bias:
+ *     [ W1 (128*3) | b1 (128) | W2 (128*128) | b2 (128) | ... | W8 | b8 | W9 (3*128) | b9 (3) ]         P = 116 483      */
+#define NDP_NSFP_W 128
+#define NDP_NSFP_LAYERS 9
+NDP_HD static inline int ndp_nsfp_off_W(int l /*1..9*/) {
+    return l == 1 ? 0 : NDP_NSFP_W * 4 + (l - 2) * (NDP_NSFP_W * NDP_NSFP_W + NDP_NSFP_W);
+}
+NDP_HD static inline int ndp_nsfp_off_b(int l) {
+    return ndp_nsfp_off_W(l) + (l == 1 ? NDP_NSFP_W * 3 : (l == NDP_NSFP_LAYERS ? 3 * NDP_NSFP_W : NDP_NSFP_W * NDP_NSFP_W));
+}
+NDP_HD static inline int ndp_nsfp_param_count(void) { return ndp_nsfp_off_b(NDP_NSFP_LAYERS) + 3; }
+
 #ifdef __cplusplus
 }
 #endif

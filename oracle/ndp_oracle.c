@@ -619,3 +619,102 @@ int ndp_o_optimize(const ndp_layer_desc *descs, const ndp_o_opt_cfg *cfg, float 
     free(grads); free(am); free(av); free(nrv); free(gnr);
     return total_steps;
 }
+
+/* ---------------------------------------------------------------- NSFP baseline
+ * Neural_Prior (nets.py:256-292): x -> L9(relu(L8(... relu(L1 x)))) ; optimize_neural_SFlow (registration.py:470-540). */
+
+static void nsfp_point_fwd(const float *P, const float x[3], float h[8][NDP_NSFP_W], float flow[3]) {
+    const float *W1 = P + ndp_nsfp_off_W(1), *b1 = P + ndp_nsfp_off_b(1);
+    for (int o = 0; o < NDP_NSFP_W; ++o) {
+        float z = fmaf(W1[3 * o + 2], x[2], fmaf(W1[3 * o + 1], x[1], fmaf(W1[3 * o], x[0], b1[o])));
+        h[0][o] = z > 0.f ? z : 0.f;
+    }
+    for (int l = 2; l <= NDP_NSFP_LAYERS - 1; ++l) {
+        const float *W = P + ndp_nsfp_off_W(l), *b = P + ndp_nsfp_off_b(l);
+        for (int o = 0; o < NDP_NSFP_W; ++o) {
+            float z = b[o];
+            for (int k = 0; k < NDP_NSFP_W; ++k) z = fmaf(W[o * NDP_NSFP_W + k], h[l - 2][k], z);
+            h[l - 1][o] = z > 0.f ? z : 0.f;
+        }
+    }
+    const float *W9 = P + ndp_nsfp_off_W(NDP_NSFP_LAYERS), *b9 = P + ndp_nsfp_off_b(NDP_NSFP_LAYERS);
+    for (int j = 0; j < 3; ++j) {
+        float z = b9[j];
+        for (int k = 0; k < NDP_NSFP_W; ++k) z = fmaf(W9[j * NDP_NSFP_W + k], h[7][k], z);
+        flow[j] = z;
+    }
+}
+
+void ndp_o_nsfp_fwd(const float *params, const float *x, int n, float *x_out, int nthreads) {
+#pragma omp parallel for num_threads(nthreads > 0 ? nthreads : 1) schedule(static)
+    for (int p = 0; p < n; ++p) {
+        float h[8][NDP_NSFP_W], flow[3];
+        nsfp_point_fwd(params, x + 3 * p, h, flow);
+        for (int a = 0; a < 3; ++a) x_out[3 * p + a] = x[3 * p + a] + flow[a];       /* registration.py:507 */
+    }
+}
+
+/* grads (P floats, overwritten) of a scalar loss given g = dL/dx_out [n][3]; points in index order */
+void ndp_o_nsfp_bwd(const float *params, const float *x, int n, const float *g, float *grads) {
+    const int P = ndp_nsfp_param_count();
+    memset(grads, 0, sizeof(float) * (size_t)P);
+    for (int p = 0; p < n; ++p) {
+        float h[8][NDP_NSFP_W], flow[3], dz[NDP_NSFP_W], dzn[NDP_NSFP_W];
+        nsfp_point_fwd(params, x + 3 * p, h, flow);
+        const float *gp = g + 3 * p;
+        const float *W9 = params + ndp_nsfp_off_W(NDP_NSFP_LAYERS);
+        float *gW9 = grads + ndp_nsfp_off_W(NDP_NSFP_LAYERS), *gb9 = grads + ndp_nsfp_off_b(NDP_NSFP_LAYERS);
+        for (int j = 0; j < 3; ++j) {
+            gb9[j] += gp[j];
+            for (int k = 0; k < NDP_NSFP_W; ++k) gW9[j * NDP_NSFP_W + k] = fmaf(gp[j], h[7][k], gW9[j * NDP_NSFP_W + k]);
+        }
+        for (int k = 0; k < NDP_NSFP_W; ++k) {
+            float s = 0.f;
+            for (int j = 0; j < 3; ++j) s = fmaf(gp[j], W9[j * NDP_NSFP_W + k], s);
+            dz[k] = h[7][k] > 0.f ? s : 0.f;
+        }
+        for (int l = NDP_NSFP_LAYERS - 1; l >= 2; --l) {
+            const float *W = params + ndp_nsfp_off_W(l);
+            float *gW = grads + ndp_nsfp_off_W(l), *gb = grads + ndp_nsfp_off_b(l);
+            for (int o = 0; o < NDP_NSFP_W; ++o) {
+                gb[o] += dz[o];
+                for (int k = 0; k < NDP_NSFP_W; ++k) gW[o * NDP_NSFP_W + k] = fmaf(dz[o], h[l - 2][k], gW[o * NDP_NSFP_W + k]);
+            }
+            for (int k = 0; k < NDP_NSFP_W; ++k) {
+                float s = 0.f;
+                for (int o = 0; o < NDP_NSFP_W; ++o) s = fmaf(dz[o], W[o * NDP_NSFP_W + k], s);
+                dzn[k] = h[l - 2][k] > 0.f ? s : 0.f;
+            }
+            memcpy(dz, dzn, sizeof dz);
+        }
+        float *gW1 = grads + ndp_nsfp_off_W(1), *gb1 = grads + ndp_nsfp_off_b(1);
+        for (int o = 0; o < NDP_NSFP_W; ++o) {
+            gb1[o] += dz[o];
+            for (int a = 0; a < 3; ++a) gW1[3 * o + a] = fmaf(dz[o], x[3 * p + a], gW1[3 * o + a]);
+        }
+    }
+}
+
+/* registration.py:504-529.  params updated in place; returns the number of Adam steps; loss_trace gets every
+ * evaluated loss; warped [S][3] = s_sample + flow of the LAST forward.                                          */
+int ndp_o_nsfp_optimize(float *params, const float *s_sample, int S, const float *t_sample, int T, int iters,
+                        int max_break_count, double ratio, double lr, int early_stop,
+                        float *warped, double *loss_trace, int trace_cap, int nthreads) {
+    const int P = ndp_nsfp_param_count();
+    float *g = (float *)malloc(sizeof(float) * 3 * (size_t)S), *grads = (float *)malloc(sizeof(float) * (size_t)P);
+    float *am = (float *)calloc((size_t)P, sizeof(float)), *av = (float *)calloc((size_t)P, sizeof(float));
+    float *d2x = (float *)malloc(sizeof(float) * (size_t)S), *d2y = (float *)malloc(sizeof(float) * (size_t)T);
+    int *ix = (int *)malloc(sizeof(int) * (size_t)S), *iy = (int *)malloc(sizeof(int) * (size_t)T);
+    int break_counter = 0, steps = 0, ntrace = 0;
+    double loss_prev = 1e6;
+    for (int i = 0; i < iters; ++i) {
+        ndp_o_nsfp_fwd(params, s_sample, S, warped, nthreads);
+        const float loss = ndp_o_chamfer(warped, S, t_sample, T, 1e9f, d2x, ix, d2y, iy, g, nthreads);
+        if (loss_trace && ntrace < trace_cap) loss_trace[ntrace++] = (double)loss;
+        if (early_stop && ndp_o_stop_check((double)loss, &break_counter, &loss_prev, max_break_count, ratio)) break;
+        ndp_o_nsfp_bwd(params, s_sample, S, g, grads);
+        ndp_o_adam(params, grads, am, av, P, ++steps, lr, 0.9, 0.999, 1e-8);
+    }
+    free(g); free(grads); free(am); free(av); free(d2x); free(d2y); free(ix); free(iy);
+    return steps;
+}

@@ -79,6 +79,14 @@ int ndp_o_optimize(const ndp_layer_desc *descs, const ndp_o_opt_cfg *cfg, float 
                    float *pts, int K, int S, const float *ldmk_t, const float *tgt, int T,
                    int *iters_per_level, double *loss_trace, int trace_cap, int nthreads);
 
+/* ---- NSFP baseline: Neural_Prior (nets.py:256-292), optimize_neural_SFlow (registration.py:470-540).
+ * Parameter layout: ndp_types.h (ndp_nsfp_off_W / ndp_nsfp_off_b).  x_out = x + MLP(x).                                  */
+void ndp_o_nsfp_fwd(const float *params, const float *x, int n, float *x_out, int nthreads);
+void ndp_o_nsfp_bwd(const float *params, const float *x, int n, const float *g, float *grads);
+int ndp_o_nsfp_optimize(float *params, const float *s_sample, int S, const float *t_sample, int T, int iters,
+                        int max_break_count, double ratio, double lr, int early_stop,
+                        float *warped, double *loss_trace, int trace_cap, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,7 @@ def lib():
         L.ndp_o_landmark.restype = ctypes.c_float
         L.ndp_o_stop_check.restype = ctypes.c_int
         L.ndp_o_optimize.restype = ctypes.c_int
+        L.ndp_o_nsfp_optimize.restype = ctypes.c_int
         _LIB = L
     return _LIB
 
@@ -169,3 +170,39 @@ def optimize(descs, params_all, pts, K, S, ldmk_t, tgt, *, k0=-8, iters=500, max
                                  int(nthreads))
     return dict(params_all=params_all, pts=pts, iters_per_level=ipl,
                 loss_trace=trace[:int(ipl.sum())], steps=steps)
+
+
+# ------------------------------------------------------------------ NSFP baseline
+NSFP_P = 128 * 4 + 7 * (128 * 128 + 128) + 3 * 128 + 3
+
+
+def nsfp_fwd(params, x, nthreads=1):
+    params, pp = _f(params)
+    x, xp = _f(x)
+    out = np.empty_like(x)
+    lib().ndp_o_nsfp_fwd(pp, xp, x.shape[0], out.ctypes.data_as(c_float_p), int(nthreads))
+    return out
+
+
+def nsfp_bwd(params, x, g):
+    params, pp = _f(params)
+    x, xp = _f(x)
+    g, gp = _f(g)
+    grads = np.zeros(NSFP_P, dtype=np.float32)
+    lib().ndp_o_nsfp_bwd(pp, xp, x.shape[0], gp, grads.ctypes.data_as(c_float_p))
+    return grads
+
+
+def nsfp_optimize(params, s_sample, t_sample, iters, max_break_count=70, ratio=0.001, lr=0.01, early_stop=True,
+                  nthreads=1, trace_cap=8192):
+    params = np.array(params[:NSFP_P], dtype=np.float32, order="C", copy=True)
+    s, sp = _f(s_sample)
+    t, tp = _f(t_sample)
+    warped = np.empty_like(s)
+    trace = np.zeros(trace_cap, dtype=np.float64)
+    steps = lib().ndp_o_nsfp_optimize(params.ctypes.data_as(c_float_p), sp, s.shape[0], tp, t.shape[0], int(iters),
+                                      int(max_break_count), ctypes.c_double(ratio), ctypes.c_double(lr),
+                                      int(bool(early_stop)), warped.ctypes.data_as(c_float_p),
+                                      trace.ctypes.data_as(c_double_p), trace_cap, int(nthreads))
+    n_eval = steps + 1 if steps < iters else steps
+    return dict(params=params, warped=warped, steps=steps, loss_trace=trace[:min(n_eval, trace_cap)])

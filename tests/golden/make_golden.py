@@ -470,6 +470,70 @@ def F10_benchmark(reg_mod, loss_mod, EasyDict, bench_pairs=8, **_):
          iters=np.array(iters), seeds=np.arange(bench_pairs))
 
 
+def F12_nsfp(nets, loss_mod, reg_mod, EasyDict, **_):
+    """NSFP baseline: Neural_Prior init / forward / parameter gradients through the Chamfer loss,
+    and optimize_neural_SFlow end to end with every evaluated loss recorded."""
+    out = {}
+    torch.manual_seed(21)
+    model = nets.Neural_Prior()
+    names = [k for k, _ in model.named_parameters()]
+    out["names"] = np.array(names)
+    for k, v in model.named_parameters():
+        a = v.detach().numpy()
+        out[f"init.{k}.sum"] = np.float64(a.astype(np.float64).sum())
+        out[f"init.{k}.abs"] = np.float64(np.abs(a.astype(np.float64)).sum())
+        out[f"init.{k}.head"] = a.reshape(-1)[:8].copy()
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(200, 3, generator=g) - 0.5
+    y = (torch.rand(180, 3, generator=g) - 0.5) * 1.1 + 0.03
+    # scale the weights up so that the flow is not vanishingly small next to x
+    with torch.no_grad():
+        for k, v in model.named_parameters():
+            if k.endswith("weight"):
+                v.mul_(1.5)
+    out["fb.x"], out["fb.y"] = x.numpy(), y.numpy()
+    flow = model(x)
+    out["fb.flow"] = flow.detach().numpy()
+    loss = loss_mod.compute_truncated_chamfer_distance((x + flow)[None], y[None], trunc=1e9)
+    loss.backward()
+    out["fb.loss"] = np.float64(loss.item())
+    for k, v in model.named_parameters():
+        out[f"fb.grad.{k}"] = v.grad.numpy().copy() if v.numel() <= 4096 else v.grad.numpy().reshape(-1)[::37].copy()
+        out[f"fb.gsum.{k}"] = np.float64(v.grad.numpy().astype(np.float64).sum())
+        out[f"fb.gabs.{k}"] = np.float64(np.abs(v.grad.numpy().astype(np.float64)).sum())
+    out["fb.scale"] = np.float32(1.5)
+    # end to end
+    src, tgt, flow_gt, overlap = synthetic_pair(7, n_total=2048)
+    cfg = EasyDict(dict(deformation_model="NSFP", device=torch.device("cpu"), iters=60, lr=0.01, max_break_count=70,
+                        break_threshold_ratio=0.001, samples=256))
+    trace = []
+    orig_cd = reg_mod.compute_truncated_chamfer_distance
+
+    def cd(*a, **k):
+        v = orig_cd(*a, **k)
+        trace.append(v.item())
+        return v
+
+    reg_mod.compute_truncated_chamfer_distance = cd
+    try:
+        torch.manual_seed(9)
+        m = reg_mod.Registration(cfg)
+        m.load_pcds(src.numpy(), tgt.numpy())
+        warped, smpl = m.register()
+    finally:
+        reg_mod.compute_truncated_chamfer_distance = orig_cd
+    assert smpl is None
+    out["e2e.src"], out["e2e.tgt"] = src.numpy(), tgt.numpy()
+    out["e2e.flow_gt"], out["e2e.overlap"] = flow_gt.numpy(), overlap.numpy()
+    out["e2e.warped"] = warped.detach().numpy()
+    out["e2e.loss_trace"] = np.array(trace, dtype=np.float64)
+    out["e2e.seed"] = np.int64(9)
+    mt = loss_mod.compute_flow_metrics(warped.detach() - src, flow_gt, overlap)
+    out["e2e.metric_keys"] = np.array(list(mt.keys()))
+    out["e2e.metric_vals"] = np.array(list(mt.values()), dtype=np.float64)
+    save("F12_nsfp", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -485,7 +549,7 @@ def main():
     todo = {
         "F1": F1_init, "F2": F2_layer_forward, "F3": F3_chamfer, "F4": F4_F5_iteration,
         "F7": F7_end_to_end, "F8": F8_metrics, "F9": F9_landmarks, "F9b": F9b_lndp_end_to_end,
-        "F10": F10_benchmark, "F11": F11_nonrigidity,
+        "F10": F10_benchmark, "F11": F11_nonrigidity, "F12": F12_nsfp,
     }
     only = [s for s in args.only.split(",") if s]
     for k, fn in todo.items():

@@ -75,9 +75,13 @@ def test_no_cpu_fallback():
     model.load_pcds(np.zeros((20, 3), np.float32), np.zeros((20, 3), np.float32))
     with pytest.raises(_native.NdpError):
         model.register()
-    cfg2 = Config(cfg, deformation_model="NSFP")
-    with pytest.raises(KeyError):
-        Registration(cfg2).register()
+    nsfp = Registration(Config(cfg, deformation_model="NSFP"))       # served baseline: same rule, GPU only
+    nsfp.load_pcds(np.zeros((20, 3), np.float32), np.zeros((20, 3), np.float32))
+    with pytest.raises(_native.NdpError):
+        nsfp.register()
+    for other in ("Nerfies", "Sinkhorn", "ED"):                      # unserved comparison baselines (registration.py:123)
+        with pytest.raises(KeyError):
+            Registration(Config(cfg, deformation_model=other)).register()
 
 
 def test_config_files_and_join_constructor():
