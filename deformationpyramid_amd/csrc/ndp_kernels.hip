@@ -819,7 +819,11 @@ extern "C" __global__ void k_grad_reduce(const float *gpart, int n_part, int p_s
 // the winning sub-chunk.  ~3.7 VALU instructions per distance instead of ~10.
 #define NN_STAGE 2048
 #define NN_SUB 16
-#define NN_QPB 512                    /* queries per workgroup */
+#define NN_QPB 512                    /* queries per workgroup (standalone operator: two per thread) */
+#ifndef NN_ENG_NQ
+#define NN_ENG_NQ 2                   /* engine: queries per thread (measured at 128 pairs: 2 -> 0.147 ms, 4 -> 0.157 ms, 8 -> 0.174 ms) */
+#endif
+#define NN_ENG_QPB (256 * NN_ENG_NQ)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 pk_dist2(f32x2 X, f32x2 Y, f32x2 Z, f32x2 qx, f32x2 qy, f32x2 qz) {
@@ -830,18 +834,25 @@ __device__ __forceinline__ f32x2 pk_dist2(f32x2 X, f32x2 Y, f32x2 Z, f32x2 qx, f
     return dd;
 }
 
+// NQ queries per thread (queries qbase + t + 256*w): the reference tile read from LDS is shared by NQ queries
+template <int NQ>
 __device__ __forceinline__ void nn_body(const float *q, int nq, const float *r, int nr, float *d2, int *idx,
                                         int qbase, float *sm /*[3][NN_STAGE]*/) {
     const int t = threadIdx.x;
     float *xs = sm, *ys = sm + NN_STAGE, *zs = sm + 2 * NN_STAGE;
-    const int i0 = qbase + t, i1 = qbase + 256 + t;
-    float qa[3] = {0.f, 0.f, 0.f}, qb[3] = {0.f, 0.f, 0.f};
-    if (i0 < nq) { qa[0] = q[3 * i0]; qa[1] = q[3 * i0 + 1]; qa[2] = q[3 * i0 + 2]; }
-    if (i1 < nq) { qb[0] = q[3 * i1]; qb[1] = q[3 * i1 + 1]; qb[2] = q[3 * i1 + 2]; }
-    const f32x2 ax = {qa[0], qa[0]}, ay = {qa[1], qa[1]}, az = {qa[2], qa[2]};
-    const f32x2 bx = {qb[0], qb[0]}, by = {qb[1], qb[1]}, bz = {qb[2], qb[2]};
-    float best0 = INFINITY, best1 = INFINITY;
-    int sc0 = -1, sc1 = -1;                               // winning sub-chunk (global index)
+    float qc[NQ][3];
+    f32x2 qx[NQ], qy[NQ], qz[NQ];
+    float best[NQ];
+    int sc_best[NQ];                                       // winning sub-chunk (global index)
+#pragma unroll
+    for (int w = 0; w < NQ; ++w) {
+        const int i = qbase + 256 * w + t;
+        qc[w][0] = qc[w][1] = qc[w][2] = 0.f;
+        if (i < nq) { qc[w][0] = q[3 * (size_t)i]; qc[w][1] = q[3 * (size_t)i + 1]; qc[w][2] = q[3 * (size_t)i + 2]; }
+        qx[w] = f32x2{qc[w][0], qc[w][0]}; qy[w] = f32x2{qc[w][1], qc[w][1]}; qz[w] = f32x2{qc[w][2], qc[w][2]};
+        best[w] = INFINITY;
+        sc_best[w] = -1;
+    }
     for (int c0 = 0; c0 < nr; c0 += NN_STAGE) {
         const int cn = min(NN_STAGE, nr - c0);
         const int cpad = (cn + NN_SUB - 1) / NN_SUB * NN_SUB;
@@ -867,7 +878,9 @@ __device__ __forceinline__ void nn_body(const float *q, int nq, const float *r, 
         __syncthreads();
         const int nsub = cpad / NN_SUB;
         for (int sc = 0; sc < nsub; ++sc) {
-            float m0 = INFINITY, m1 = INFINITY;
+            float m[NQ];
+#pragma unroll
+            for (int w = 0; w < NQ; ++w) m[w] = INFINITY;
 #pragma unroll
             for (int u = 0; u < NN_SUB / 4; ++u) {
                 const int o = sc * NN_SUB + 4 * u;
@@ -875,34 +888,34 @@ __device__ __forceinline__ void nn_body(const float *q, int nq, const float *r, 
                 const float4 Y = *reinterpret_cast<const float4 *>(ys + o);
                 const float4 Z = *reinterpret_cast<const float4 *>(zs + o);
                 const f32x2 X0 = {X.x, X.y}, X1 = {X.z, X.w}, Y0 = {Y.x, Y.y}, Y1 = {Y.z, Y.w}, Z0 = {Z.x, Z.y}, Z1 = {Z.z, Z.w};
-                const f32x2 a0 = pk_dist2(X0, Y0, Z0, ax, ay, az), a1 = pk_dist2(X1, Y1, Z1, ax, ay, az);
-                const f32x2 b0 = pk_dist2(X0, Y0, Z0, bx, by, bz), b1 = pk_dist2(X1, Y1, Z1, bx, by, bz);
-                m0 = fminf(fminf(m0, a0.x), a0.y); m0 = fminf(fminf(m0, a1.x), a1.y);
-                m1 = fminf(fminf(m1, b0.x), b0.y); m1 = fminf(fminf(m1, b1.x), b1.y);
+#pragma unroll
+                for (int w = 0; w < NQ; ++w) {
+                    const f32x2 a0 = pk_dist2(X0, Y0, Z0, qx[w], qy[w], qz[w]), a1 = pk_dist2(X1, Y1, Z1, qx[w], qy[w], qz[w]);
+                    m[w] = fminf(fminf(m[w], a0.x), a0.y);
+                    m[w] = fminf(fminf(m[w], a1.x), a1.y);
+                }
             }
             const int gsc = (c0 / NN_SUB) + sc;
-            if (m0 < best0) { best0 = m0; sc0 = gsc; }
-            if (m1 < best1) { best1 = m1; sc1 = gsc; }
+#pragma unroll
+            for (int w = 0; w < NQ; ++w)
+                if (m[w] < best[w]) { best[w] = m[w]; sc_best[w] = gsc; }
         }
     }
     // exact lowest index inside the winning sub-chunk (same arithmetic -> bitwise equality is safe)
 #pragma unroll
-    for (int w = 0; w < 2; ++w) {
-        const int i = w ? i1 : i0;
+    for (int w = 0; w < NQ; ++w) {
+        const int i = qbase + 256 * w + t;
         if (i >= nq) continue;
-        const float best = w ? best1 : best0;
-        const int sc = w ? sc1 : sc0;
-        const float qx = w ? qb[0] : qa[0], qy = w ? qb[1] : qa[1], qz = w ? qb[2] : qa[2];
         int bi = -1;
-        if (sc >= 0) {
-            const int j0 = sc * NN_SUB, j1 = min(j0 + NN_SUB, nr);
+        if (sc_best[w] >= 0) {
+            const int j0 = sc_best[w] * NN_SUB, j1 = min(j0 + NN_SUB, nr);
             for (int j = j1 - 1; j >= j0; --j) {
-                const float dx = qx - r[3 * j], dy = qy - r[3 * j + 1], dz = qz - r[3 * j + 2];
+                const float dx = qc[w][0] - r[3 * (size_t)j], dy = qc[w][1] - r[3 * (size_t)j + 1], dz = qc[w][2] - r[3 * (size_t)j + 2];
                 const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-                if (dd == best) bi = j;                   // descending j: the last hit is the lowest index
+                if (dd == best[w]) bi = j;                // descending j: the last hit is the lowest index
             }
         }
-        d2[i] = best;
+        d2[i] = best[w];
         idx[i] = bi;
     }
 }
@@ -911,8 +924,8 @@ extern "C" __global__ void __launch_bounds__(256)
 k_nn(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y, int *idx_y) {
     __shared__ __attribute__((aligned(16))) float sm[3 * NN_STAGE];
     const int bx = (S + NN_QPB - 1) / NN_QPB;
-    if ((int)blockIdx.x < bx) nn_body(x, S, y, T, d2x, idx_x, blockIdx.x * NN_QPB, sm);
-    else nn_body(y, T, x, S, d2y, idx_y, (blockIdx.x - bx) * NN_QPB, sm);
+    if ((int)blockIdx.x < bx) nn_body<2>(x, S, y, T, d2x, idx_x, blockIdx.x * NN_QPB, sm);
+    else nn_body<2>(y, T, x, S, d2y, idx_y, (blockIdx.x - bx) * NN_QPB, sm);
 }
 
 // sum_i sqrt(d2_i) [d2_i < trunc], deterministic block reduction (all 256 threads get the value)
@@ -1043,17 +1056,17 @@ k_eng_nn(ndp_engine e, int parity) {
     if (gm.S == 0 || e.w_cd == 0.f) return;
     const float *xw = e.pts + ((size_t)b * 2 + (st.cur ^ 1)) * e.n_cap * 3 + 3 * gm.K;
     const float *y = e.tgt + (size_t)b * e.t_cap * 3;
-    const int bx = (e.n_cap + NN_QPB - 1) / NN_QPB;
+    const int bx = (e.n_cap + NN_ENG_QPB - 1) / NN_ENG_QPB;
     if ((int)blockIdx.x < bx) {
-        const int qb = blockIdx.x * NN_QPB;
+        const int qb = blockIdx.x * NN_ENG_QPB;
         if (qb >= gm.S) return;
-        nn_body(xw, gm.S, y, gm.T, e.d2x + (size_t)b * e.n_cap, e.idx_x + (size_t)b * e.n_cap, qb, sm);
+        nn_body<NN_ENG_NQ>(xw, gm.S, y, gm.T, e.d2x + (size_t)b * e.n_cap, e.idx_x + (size_t)b * e.n_cap, qb, sm);
     } else {
-        const int qb = (blockIdx.x - bx) * NN_QPB;
+        const int qb = (blockIdx.x - bx) * NN_ENG_QPB;
         float *d2y = e.d2y + (size_t)b * e.t_cap;
         int *iy = e.idx_y + (size_t)b * e.t_cap;
-        if (qb < gm.T) nn_body(y, gm.T, xw, gm.S, d2y, iy, qb, sm);
-        for (int j = qb + threadIdx.x; j < min(qb + NN_QPB, e.t_cap); j += 256)
+        if (qb < gm.T) nn_body<NN_ENG_NQ>(y, gm.T, xw, gm.S, d2y, iy, qb, sm);
+        for (int j = qb + threadIdx.x; j < min(qb + NN_ENG_QPB, e.t_cap); j += 256)
             if (j >= gm.T) iy[j] = -1;             // keep the -1 padding the gradient scan relies on
     }
 }
@@ -1900,7 +1913,7 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
     hipStream_t s = (hipStream_t)stream;
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
-    const dim3 g_nn((e->n_cap + NN_QPB - 1) / NN_QPB + (e->t_cap + NN_QPB - 1) / NN_QPB, e->B);
+    const dim3 g_nn((e->n_cap + NN_ENG_QPB - 1) / NN_ENG_QPB + (e->t_cap + NN_ENG_QPB - 1) / NN_ENG_QPB, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const dim3 g_loss((e->n_cap + 255) / 256, e->B);
     for (int k = 0; k < n_ticks; ++k) {
@@ -1930,7 +1943,7 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
     hipStream_t s = (hipStream_t)stream;
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
-    const dim3 g_nn((e->n_cap + NN_QPB - 1) / NN_QPB + (e->t_cap + NN_QPB - 1) / NN_QPB, e->B);
+    const dim3 g_nn((e->n_cap + NN_ENG_QPB - 1) / NN_ENG_QPB + (e->t_cap + NN_ENG_QPB - 1) / NN_ENG_QPB, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const bool nn = e->w_cd != 0.f && e->d2x;
     const dim3 g_loss((e->n_cap + 255) / 256, e->B);
