@@ -4,19 +4,23 @@
 // Design:
 //   * One workgroup = 256 threads = 4 wave64.  A tile is 64 points.  Wave w owns output columns
 //     [32w, 32w+32) of every 128-wide layer.
-//   * The two 128x128 weight matrices of a level are WEIGHT-STATIONARY IN REGISTERS: each lane
-//     holds its 64-float slice of W1 and of W2 in the v_mfma_f32_32x32x2_f32 B-operand layout
-//     (forward: W[o][k] slices; backward: the transposed slices) for the whole life of the
-//     workgroup, so the only per-MFMA operand fetch is one LDS read of the activation.
+//   * The 128x128 weight matrices are WEIGHT-STATIONARY IN REGISTERS: each lane holds its 64-float
+//     slice in the v_mfma_f32_32x32x2_f32 B-operand layout (forward: W[o][k] slices of W1 and W2;
+//     backward, one layer per kernel: the transposed slice) for the whole life of the workgroup,
+//     so the only per-MFMA operand fetch is one LDS read of the activation.
 //   * Activations move through two [64][132] LDS tiles (+4 float pad: ds_read_b128 of a column
 //     block is bank-conflict free).  fp32 in, fp32 accumulate: the MFMA result is bitwise an fmaf
-//     chain, which is what the 1e-4 parity budget needs.
-//   * The backward keeps dW1 and dW2 (2 x 128x128) in accumulator registers across all of the
-//     workgroup's tiles and writes ONE partial per workgroup; partials are folded in index order
-//     by the Adam kernel -- no float atomics anywhere, results are bit-reproducible.
+//     chain, which is what the 1e-4 parity budget needs.  Everything that is a small GEMM runs on
+//     the matrix pipe too (6 -> 128 input layer, the 16-wide heads and the 6-wide input-layer
+//     gradient on v_mfma_f32_16x16x4_f32): VALU loops over LDS next to MFMA phases are what a tile
+//     used to wait for.
+//   * The backward keeps one 128x128 dW in accumulator registers across all of the workgroup's tiles
+//     and writes ONE partial per workgroup; partials are folded in index order by the Adam kernel --
+//     no float atomics anywhere, results are bit-reproducible.
 //   * The batched engine advances B independent pairs per launch, every pair at its own level and
 //     iteration; the early-stop rule runs on the device in double, so the host never syncs per
-//     iteration (the reference syncs three times: registration.py:226-232).
+//     iteration (the reference syncs three times: registration.py:226-232).  Slot refill, pair
+//     preparation and the final all-point warp are batched single launches as well.
 //
 // Compile: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (explicit fmaf only).
 #include "ndp_device.h"
@@ -133,28 +137,6 @@ __device__ __forceinline__ void store_tile_from_lds(const float *src /*LDS*/, fl
         const int idx = t + 256 * i;
         reinterpret_cast<float4 *>(dst)[idx] = *reinterpret_cast<const float4 *>(src + (idx >> 5) * NDP_LD + 4 * (idx & 31));
     }
-}
-
-// one quarter (16 k-steps) of tile_gemm_64x32 with a 16-float slice of the lane's weight operand
-__device__ __forceinline__ void tile_gemm_quarter(const float *in /*LDS [64][LD]*/, const float (&w)[16], int q,
-                                                  int l31, int h, f32x16 &acc0, f32x16 &acc1) {
-    const float *r0 = in + l31 * NDP_LD + 64 * h + 16 * q;
-    const float *r1 = r0 + 32 * NDP_LD;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float4 a0 = *reinterpret_cast<const float4 *>(r0 + 4 * i);
-        const float4 a1 = *reinterpret_cast<const float4 *>(r1 + 4 * i);
-        acc0 = MFMA32(a0.x, w[4 * i], acc0);     acc1 = MFMA32(a1.x, w[4 * i], acc1);
-        acc0 = MFMA32(a0.y, w[4 * i + 1], acc0); acc1 = MFMA32(a1.y, w[4 * i + 1], acc1);
-        acc0 = MFMA32(a0.z, w[4 * i + 2], acc0); acc1 = MFMA32(a1.z, w[4 * i + 2], acc1);
-        acc0 = MFMA32(a0.w, w[4 * i + 3], acc0); acc1 = MFMA32(a1.w, w[4 * i + 3], acc1);
-    }
-}
-// w[i] = W[64h + 16q + i][32wv + l31]: quarter q of the backward (transposed) operand slice, from L2
-__device__ __forceinline__ void load_w_bwd_quarter(const float *W, int q, int wv, int l31, int h, float (&w)[16]) {
-    const float *src = W + (64 * h + 16 * q) * NDP_W + 32 * wv + l31;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) w[i] = src[i * NDP_W];
 }
 
 // C/D layout of v_mfma_f32_32x32x2_f32: reg r of lane l holds row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31
@@ -426,7 +408,6 @@ enum : int {
     LB_TOTAL = LB_PE + 6 * 64
 };
 static constexpr int kSmemBwdBytes = LB_TOTAL * 4;       // 73.2 KB: two workgroups per CU
-#define NDP_NHP 12                                        // head rows carried in registers (>= 11 used)
 
 struct BwdJob {
     const float *params;
@@ -1617,7 +1598,7 @@ static int check_desc(const ndp_layer_desc *d) {
 static bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 static int set_smem(const void *fn, int bytes) {
-    static thread_local const void *done[8];
+    static thread_local const void *done[32];
     for (auto d : done) if (d == fn) return 0;
     HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes), "hipFuncSetAttribute");
     for (auto &d : done) if (!d) { d = fn; break; }
