@@ -110,7 +110,10 @@ __device__ __forceinline__ void load_w_bwd(const float *W, int wv, int l31, int 
     for (int i = 0; i < 64; ++i) w[i] = src[i * NDP_W];
 }
 
-// out[p][32wv + l31] = sum_k in[p][k] * (w-slice)   for the 64 points of a tile; acc pre-loaded by caller
+// OUT^T[o][p] += sum_k W[o][k] * in[p][k] for the 64 points of a tile: the weight slice is the MFMA A operand
+// (row m = this lane's output feature 32wv + l31), the activation row of point l31 (+32) the B operand.  In the
+// resulting C layout a lane holds point p = l31 (acc0) / l31 + 32 (acc1) and, per register group g = r >> 2, the FOUR
+// CONSECUTIVE output features 32wv + 8g + 4h + (r & 3): epilogues read/write row-major tiles with b128 LDS accesses.
 __device__ __forceinline__ void tile_gemm_64x32(const float *in /*LDS [64][LD]*/, const float (&w)[64],
                                                 int l31, int h, f32x16 &acc0, f32x16 &acc1) {
     const float *r0 = in + l31 * NDP_LD + 64 * h;
@@ -119,13 +122,51 @@ __device__ __forceinline__ void tile_gemm_64x32(const float *in /*LDS [64][LD]*/
     for (int i = 0; i < 16; ++i) {
         const float4 a0 = *reinterpret_cast<const float4 *>(r0 + 4 * i);
         const float4 a1 = *reinterpret_cast<const float4 *>(r1 + 4 * i);
-        acc0 = MFMA32(a0.x, w[4 * i], acc0);     acc1 = MFMA32(a1.x, w[4 * i], acc1);
-        acc0 = MFMA32(a0.y, w[4 * i + 1], acc0); acc1 = MFMA32(a1.y, w[4 * i + 1], acc1);
-        acc0 = MFMA32(a0.z, w[4 * i + 2], acc0); acc1 = MFMA32(a1.z, w[4 * i + 2], acc1);
-        acc0 = MFMA32(a0.w, w[4 * i + 3], acc0); acc1 = MFMA32(a1.w, w[4 * i + 3], acc1);
+        acc0 = MFMA32(w[4 * i], a0.x, acc0);     acc1 = MFMA32(w[4 * i], a1.x, acc1);
+        acc0 = MFMA32(w[4 * i + 1], a0.y, acc0); acc1 = MFMA32(w[4 * i + 1], a1.y, acc1);
+        acc0 = MFMA32(w[4 * i + 2], a0.z, acc0); acc1 = MFMA32(w[4 * i + 2], a1.z, acc1);
+        acc0 = MFMA32(w[4 * i + 3], a0.w, acc0); acc1 = MFMA32(w[4 * i + 3], a1.w, acc1);
         // keep the compiler from hoisting all 32 operand reads to the top (64 extra live VGPRs -> spills
         // at the 256-register budget of two workgroups per CU); 4 iterations in flight are plenty
         if ((i & 3) == 3) asm volatile("" ::: "memory");
+    }
+}
+// accumulators that start at the layer's bias: one extra MFMA k-step with A = (bias, 0), B = (1, 0) puts bias[o] into
+// every element exactly (0 + b * 1), so the chain stays "bias, then k = 0 .. K-1" without 16 bias registers per lane
+__device__ __forceinline__ void acc_init_bias(float bias_lane, int h, f32x16 &acc0, f32x16 &acc1) {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    const float a = h == 0 ? bias_lane : 0.f, b = h == 0 ? 1.0f : 0.f;
+    acc0 = MFMA32(a, b, z);
+    acc1 = MFMA32(a, b, z);
+}
+// ReLU epilogue of tile_gemm_64x32: [p][32wv + 8g + 4h .. +3] <- max(acc, 0), eight ds_write_b128 per lane
+__device__ __forceinline__ void epilogue_relu(const f32x16 &acc0, const f32x16 &acc1, float *out /*LDS [64][LD]*/,
+                                              int wv, int l31, int h) {
+    float *o0 = out + l31 * NDP_LD + 32 * wv + 4 * h, *o1 = o0 + 32 * NDP_LD;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4 *>(o0 + 8 * g) = make_float4(fmaxf(acc0[4 * g], 0.f), fmaxf(acc0[4 * g + 1], 0.f),
+                                                                fmaxf(acc0[4 * g + 2], 0.f), fmaxf(acc0[4 * g + 3], 0.f));
+        *reinterpret_cast<float4 *>(o1 + 8 * g) = make_float4(fmaxf(acc1[4 * g], 0.f), fmaxf(acc1[4 * g + 1], 0.f),
+                                                                fmaxf(acc1[4 * g + 2], 0.f), fmaxf(acc1[4 * g + 3], 0.f));
+    }
+}
+// backward epilogue of tile_gemm_64x32: z = d * [hmask > 0] -> zout (same tile coordinates), b128 reads and writes
+__device__ __forceinline__ void epilogue_mask(const f32x16 &d0, const f32x16 &d1, const float *hmask /*LDS*/,
+                                              float *zout /*LDS*/, int wv, int l31, int h) {
+    const int off = l31 * NDP_LD + 32 * wv + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(hmask + off + 8 * g);
+        const float4 m1 = *reinterpret_cast<const float4 *>(hmask + off + 32 * NDP_LD + 8 * g);
+        *reinterpret_cast<float4 *>(zout + off + 8 * g) =
+            make_float4(m0.x > 0.f ? d0[4 * g] : 0.f, m0.y > 0.f ? d0[4 * g + 1] : 0.f,
+                        m0.z > 0.f ? d0[4 * g + 2] : 0.f, m0.w > 0.f ? d0[4 * g + 3] : 0.f);
+        *reinterpret_cast<float4 *>(zout + off + 32 * NDP_LD + 8 * g) =
+            make_float4(m1.x > 0.f ? d1[4 * g] : 0.f, m1.y > 0.f ? d1[4 * g + 1] : 0.f,
+                        m1.z > 0.f ? d1[4 * g + 2] : 0.f, m1.w > 0.f ? d1[4 * g + 3] : 0.f);
     }
 }
 
@@ -216,21 +257,14 @@ __device__ __forceinline__ void fwd_tile_core(const HeadCfg &hc, const FwdWeight
     // ---- layer 0 (MFMA, bitwise the k = 0..5 fmaf chain starting from the bias) -> bufA
     {
         f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = fw.bias0; acc1[r] = fw.bias0; }
+        acc_init_bias(fw.bias0, h, acc0, acc1);
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const float a0 = pe[l31 * 9 + 2 * ks + h], a1 = pe[(l31 + 32) * 9 + 2 * ks + h];
-            acc0 = MFMA32(a0, fw.w0b[ks], acc0);
-            acc1 = MFMA32(a1, fw.w0b[ks], acc1);
+            acc0 = MFMA32(fw.w0b[ks], a0, acc0);
+            acc1 = MFMA32(fw.w0b[ks], a1, acc1);
         }
-        const int col = 32 * wv + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mfma_row(r, h);
-            bufA[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
-            bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
-        }
+        epilogue_relu(acc0, acc1, bufA, wv, l31, h);
     }
     PT(2);
     __syncthreads();
@@ -238,17 +272,10 @@ __device__ __forceinline__ void fwd_tile_core(const HeadCfg &hc, const FwdWeight
     // ---- layer 1 (MFMA) bufA -> bufB ; h0 goes to HBM as float4 rows while the matrix pipe works
     {
         f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = fw.bias1; acc1[r] = fw.bias1; }
+        acc_init_bias(fw.bias1, h, acc0, acc1);
         if (io.act) store_tile_from_lds(bufA, io.act + (size_t)base * NDP_W);
         tile_gemm_64x32(bufA, fw.w1, l31, h, acc0, acc1);
-        const int col = 32 * wv + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mfma_row(r, h);
-            bufB[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
-            bufB[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
-        }
+        epilogue_relu(acc0, acc1, bufB, wv, l31, h);
     }
     PT(4);
     __syncthreads();
@@ -256,17 +283,10 @@ __device__ __forceinline__ void fwd_tile_core(const HeadCfg &hc, const FwdWeight
     // ---- layer 2 (MFMA) bufB -> bufA ; h1 -> HBM
     {
         f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = fw.bias2; acc1[r] = fw.bias2; }
+        acc_init_bias(fw.bias2, h, acc0, acc1);
         if (io.act) store_tile_from_lds(bufB, io.act + ((size_t)io.plane + base) * NDP_W);
         tile_gemm_64x32(bufB, fw.w2, l31, h, acc0, acc1);
-        const int col = 32 * wv + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mfma_row(r, h);
-            bufA[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
-            bufA[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
-        }
+        epilogue_relu(acc0, acc1, bufA, wv, l31, h);
     }
     PT(6);
     __syncthreads();                                                                          // bufB (h1) is dead from here
@@ -601,13 +621,7 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
             PT(3);
             // dz1 goes through LDS so that HBM sees coalesced float4 rows (and the epilogue needs one base
             // address instead of 32 per-element addresses, which used to cost 58 spilled registers)
-            const int col = 32 * wv + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, h);
-                bufB[row * NDP_LD + col] = bufA[row * NDP_LD + col] > 0.f ? d0[r] : 0.f;
-                bufB[(row + 32) * NDP_LD + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? d1[r] : 0.f;
-            }
+            epilogue_mask(d0, d1, bufA, bufB, wv, l31, h);
         }
         PT(4);
         __syncthreads();
@@ -623,7 +637,7 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
 }
 
 // hidden layer 1 and the input layer: dW1 += dz1^T h0 ; db1 ; dh0 = dz1 W1 ; dz0 = dh0 * [h0 > 0] ;
-// dW0 += dz0^T pe (16x16x4 MFMA: rows = the 6 posenc channels, columns = this wave's 32 outputs) ; db0
+// [dW0 | db0]^T += [pe | 1]^T dz0 (16x16x4 MFMA: rows = the 6 posenc channels and a row of ones, columns = this wave's 32 outputs)
 __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
     const int l15 = lane & 15, lk = lane >> 4;
@@ -637,11 +651,10 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dW1[m][r] = 0.f;
-    f32x4 gW0a, gW0b;                              // dW0^T[c][o]: c = 4*lk + r, o = 32wv + l15 (a) / + 16 (b)
+    f32x4 gW0a, gW0b;                              // [dW0 | db0]^T[c][o]: c = 4*lk + r (c = 6: db0), o = 32wv + l15 (a) / + 16 (b)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { gW0a[r] = 0.f; gW0b[r] = 0.f; }
     float gb1[4] = {0.f, 0.f, 0.f, 0.f};
-    float gb0 = 0.f;                               // column 32wv + l31, the rows this lane holds in the MFMA C layout
 
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
@@ -675,31 +688,19 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
         PT(2);
         __syncthreads();
         PT(3);
-        // ---- dz0 = dh0 * [h0 > 0] -> bufB ; db0 straight from the registers
-        {
-            const int col = 32 * wv + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, h);
-                const float z0 = bufA[row * NDP_LD + col] > 0.f ? d0[r] : 0.f;
-                const float z1 = bufA[(row + 32) * NDP_LD + col] > 0.f ? d1[r] : 0.f;
-                bufB[row * NDP_LD + col] = z0;
-                bufB[(row + 32) * NDP_LD + col] = z1;
-                gb0 += z0;
-                gb0 += z1;
-            }
-        }
+        // ---- dz0 = dh0 * [h0 > 0] -> bufB
+        epilogue_mask(d0, d1, bufA, bufB, wv, l31, h);
         PT(4);
         __syncthreads();
         PT(5);
-        // ---- dW0^T += pe^T dz0 on the 16x16x4 MFMA: A[c][p] = pe[c][p] (c < 6), B[p][o] = dz0[p][o]
+        // ---- [dW0 | db0]^T += [pe | 1]^T dz0 on the 16x16x4 MFMA: A[c][p] = pe[c][p] (c < 6), 1 (c = 6), B[p][o] = dz0[p][o]
         {
             const float *ap = pe + (l15 < 6 ? l15 : 0) * 64 + lk;
             const float *bp = bufB + lk * NDP_LD + 32 * wv + l15;
 #pragma unroll 4
             for (int ks = 0; ks < 16; ++ks) {
                 float a = ap[4 * ks];
-                if (l15 >= 6) a = 0.f;
+                if (l15 >= 6) a = l15 == 6 ? 1.0f : 0.f;
                 const float b0 = bp[4 * ks * NDP_LD], b1 = bp[4 * ks * NDP_LD + 16];
                 gW0a = MFMA16(a, b0, gW0a);
                 gW0b = MFMA16(a, b1, gW0b);
@@ -711,23 +712,21 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
     }
     float *G = job.gpart;
     store_dW(G + ndp_off_Wi(&dd, 1), dW1, wv, l31, h);
-    {   // dW0[o][c]: lane holds c = 4*lk + r for its two columns
-        float *gw0 = G + ndp_off_W0(&dd);
+    {   // dW0[o][c] (c < 6) and db0[o] (c = 6): lane holds c = 4*lk + r for its two columns
+        float *gw0 = G + ndp_off_W0(&dd), *gb0 = G + ndp_off_b0(&dd);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = 4 * lk + r;
             if (c < 6) {
                 gw0[(32 * wv + l15) * 6 + c] = gW0a[r];
                 gw0[(32 * wv + 16 + l15) * 6 + c] = gW0b[r];
+            } else if (c == 6) {
+                gb0[32 * wv + l15] = gW0a[r];
+                gb0[32 * wv + 16 + l15] = gW0b[r];
             }
         }
     }
     colsum_finish(gb1, sm + LB_BUFA, G + ndp_off_bi(&dd, 1));
-    __syncthreads();
-    float *sc = sm + LB_BUFA;
-    if (h == 1) sc[32 * wv + l31] = gb0;
-    __syncthreads();
-    if (h == 0) G[ndp_off_b0(&dd) + 32 * wv + l31] = gb0 + sc[32 * wv + l31];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1376,16 +1375,9 @@ k_nsfp_dense(const float *W, const float *b, const float *hin, float *hout, int 
         load_tile_to_lds(hin + (size_t)tile * NDP_TILE * NDP_W, bufA);
         __syncthreads();
         f32x16 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { acc0[r] = bias; acc1[r] = bias; }
+        acc_init_bias(bias, h, acc0, acc1);
         tile_gemm_64x32(bufA, w, l31, h, acc0, acc1);
-        const int col = 32 * wv + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = mfma_row(r, h);
-            bufB[row * NDP_LD + col] = acc0[r] > 0.f ? acc0[r] : 0.f;
-            bufB[(row + 32) * NDP_LD + col] = acc1[r] > 0.f ? acc1[r] : 0.f;
-        }
+        epilogue_relu(acc0, acc1, bufB, wv, l31, h);
         __syncthreads();
         store_tile_from_lds(bufB, hout + (size_t)tile * NDP_TILE * NDP_W);
         __syncthreads();
