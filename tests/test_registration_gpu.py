@@ -207,3 +207,23 @@ def test_shape_transfer_driver_on_generated_meshes(tmp_path):
     d0 = torch.cdist(torch.from_numpy(sv).cuda(), tc)
     cd0 = d0.min(1).values.mean().item() + d0.min(0).values.mean().item()
     assert cd0 > 1.0 and cd < 0.15 * cd0, (cd0, cd, out.stdout[-500:])
+
+
+def test_eval_drivers_run_end_to_end(tmp_path):
+    """eval_nolearned.py (NDP, batched) and eval_supervised.py (LNDP with precomputed / synthetic landmarks) as
+    subprocesses: the landmark-guided run must register the synthetic pairs almost exactly (AccS 100 %)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "eval_supervised.py"), "--config",
+                          os.path.join(root, "config", "LNDP.yaml"), "--synthetic", "6", "--batched"],
+                         capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"full-epe: ([0-9.]+)\s+full-AccS: ([0-9.]+)", out.stdout)
+    assert m and float(m.group(1)) < 1.5 and float(m.group(2)) > 99.0, out.stdout[-800:]
+    out = subprocess.run([sys.executable, os.path.join(root, "eval_nolearned.py"), "--config",
+                          os.path.join(root, "config", "NDP.yaml"), "--synthetic", "4", "--batched"],
+                         capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert re.search(r"4/4: full-epe: [0-9.]+", out.stdout), out.stdout[-800:]
