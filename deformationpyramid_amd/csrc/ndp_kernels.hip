@@ -1052,9 +1052,9 @@ k_eng_nn(ndp_engine e, int parity) {
 }
 
 // Loss, early-stop decision and dL/dx' for every pair (one launch per tick).
-//   workgroup (0, b): loss (registration.py:193-212; loss.py:185-258), the stop rule in double
+//   last workgroup of a pair: loss (registration.py:193-212; loss.py:185-258), the stop rule in double
 //                     (registration.py:226-232) and the pair's next state;
-//   every workgroup : the gradient of the loss wrt its 256 warped points -- own nearest-neighbour
+//   the others      : the gradient of the loss wrt their 256 warped points -- own nearest-neighbour
 //                     term, then the targets whose nearest source point it is, in ascending target
 //                     index (the order a sequential CPU scatter-add produces), no atomics.
 #define LG_CHUNK 8192
@@ -1068,7 +1068,7 @@ k_eng_loss(ndp_engine e, int parity) {
     const ndp_pair_state st = e.state[parity * e.B + b];
     ndp_pair_state *nst = e.state + (size_t)(parity ^ 1) * e.B + b;
     if (st.level >= e.m) {
-        if (blockIdx.x == 0 && t == 0) { ndp_pair_state c = st; c.decision = NDP_DEC_IDLE; *nst = c; }
+        if (blockIdx.x == gridDim.x - 1 && t == 0) { ndp_pair_state c = st; c.decision = NDP_DEC_IDLE; *nst = c; }
         return;
     }
     const ndp_pair_geom gm = e.geom[b];
@@ -1083,7 +1083,7 @@ k_eng_loss(ndp_engine e, int parity) {
     const bool use_reg = e.w_reg > 0.f && hcl.nonrig;
     const float *hrec = e.heads + (size_t)b * e.n_cap * NDP_HROW;
 
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == gridDim.x - 1) {                 // the extra workgroup of the pair: loss + decision, concurrently with the gradient workgroups
         float loss = 0.f;
         if (gm.K > 0) loss = sq_sum(x_out, ldmk_t, gm.K, red) * (1.0f / (float)gm.K);
         if (use_cd) {
@@ -1141,6 +1141,7 @@ k_eng_loss(ndp_engine e, int parity) {
             // (written straight to memory: a run-time index into the private copy would push it to scratch)
             if (decision != NDP_DEC_STEP) nst->evals_per_level[st.level] = st.iter + 1;
         }
+        return;
     }
     // ---- gradient of the loss wrt the warped points of this workgroup
     const int p = blockIdx.x * 256 + t;
@@ -1888,7 +1889,7 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
     const dim3 g_lvl(e->G, e->B);
     const dim3 g_nn((e->n_cap + NN_ENG_QPB - 1) / NN_ENG_QPB + (e->t_cap + NN_ENG_QPB - 1) / NN_ENG_QPB, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
-    const dim3 g_loss((e->n_cap + 255) / 256, e->B);
+    const dim3 g_loss((e->n_cap + 255) / 256 + 1, e->B);   // + 1: the loss / decision workgroup
     for (int k = 0; k < n_ticks; ++k) {
         const int parity = (tick0 + k) & 1;
         hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
@@ -1919,7 +1920,7 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
     const dim3 g_nn((e->n_cap + NN_ENG_QPB - 1) / NN_ENG_QPB + (e->t_cap + NN_ENG_QPB - 1) / NN_ENG_QPB, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const bool nn = e->w_cd != 0.f && e->d2x;
-    const dim3 g_loss((e->n_cap + 255) / 256, e->B);
+    const dim3 g_loss((e->n_cap + 255) / 256 + 1, e->B);   // + 1: the loss / decision workgroup
     const int per = 8;
     hipEvent_t *ev = new hipEvent_t[(size_t)n_ticks * per];
     for (int i = 0; i < n_ticks * per; ++i) (void)hipEventCreate(&ev[i]);
