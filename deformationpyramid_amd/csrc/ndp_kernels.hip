@@ -1057,7 +1057,7 @@ k_eng_nn(ndp_engine e, int parity) {
 //   the others      : the gradient of the loss wrt their 256 warped points -- own nearest-neighbour
 //                     term, then the targets whose nearest source point it is, in ascending target
 //                     index (the order a sequential CPU scatter-add produces), no atomics.
-#define LG_CHUNK 8192
+#define LG_CHUNK 2048
 extern "C" __global__ void __launch_bounds__(256)
 k_eng_loss(ndp_engine e, int parity) {
     __shared__ float red[256];
