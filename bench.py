@@ -227,10 +227,14 @@ def main():
                  "k_eng_update": 12 * P, "k_eng_loss": 4 * (S + T)}
         ach = flops[dom] * active / (prof[dom] * 1e-3) / 1e12
         tick_ms = sum(prof.values())
+        traffic = pmc_traffic(dom, active)
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / FP32_PEAK_TFLOPS, "traffic": pmc_traffic(dom, active),
+                           "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic,
                            "avg_launch_ms": prof[dom], "pairs_per_launch": active,
                            "algorithmic_flop_per_pair_launch": flops[dom]}
+        if traffic:                                   # the other ceiling, for the record: HBM bytes/s of the same kernel vs 8 TB/s
+            out["roofline"]["hbm_tbps"] = traffic / (prof[dom] * 1e-3) / 1e12
+            out["roofline"]["hbm_frac"] = out["roofline"]["hbm_tbps"] / 8.0
         out["kernels_ms_per_tick"] = prof
         out["tick"] = {"ms": tick_ms, "achieved_tflops": algorithmic_flops(S, T, P) * active / (tick_ms * 1e-3) / 1e12}
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
