@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slots", type=int, default=128, help="pairs resident per GPU (= pairs per step per GPU)")
-    ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 16 x slots)")
+    ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 32 x slots)")
     ap.add_argument("--chunk", type=int, default=4, help="ticks between host polls")
     ap.add_argument("--engines", type=int, default=2, help="independent engines (HIP streams) per GPU, `slots` pairs each")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -146,7 +146,7 @@ def main():
 
     cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=local_rank)
     B = args.slots
-    NP = args.pairs_per_step or 16 * B
+    NP = args.pairs_per_step or 32 * B
     # inputs resident in HBM before the timed region
     pairs, gts = [], []
     for i in range(NP):
