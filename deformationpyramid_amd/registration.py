@@ -51,6 +51,81 @@ class _Prepared:
         self.buf = self.store = self.perm_s = self.perm_t = self.tgt_pcd = self.ldmk_s = self.ldmk_t = None
 
 
+class _BatchCtx:
+    """What the lanes of one register_batch call share."""
+    __slots__ = ("reg", "preps", "next_prepared", "fin_stream", "main", "chunk", "m", "exhausted")
+
+    def __init__(self, reg, preps, next_prepared, fin_stream, main, chunk, m):
+        self.reg, self.preps, self.next_prepared = reg, preps, next_prepared
+        self.fin_stream, self.main, self.chunk, self.m = fin_stream, main, chunk, m
+        self.exhausted = False
+
+
+class _Lane:
+    """One engine on one stream.  Pipelined control: the states of chunk k are read back while chunk k+1
+    runs, so the GPU never waits for the host; a slot that finishes in chunk k is refilled before chunk k+2.
+    Refills of one round go up in ONE launch (k_eng_load), the final all-point warps of the pairs that
+    finished in one chunk in ONE launch (k_pyramid_fwd) on the shared side stream."""
+
+    def __init__(self, ctx, eng, stream):
+        self.ctx, self.eng, self.stream = ctx, eng, stream
+        self.fin_done = {}                               # slot -> event: its parameters have been consumed
+        self.active, self.free = {}, list(range(eng.B))  # active: slot -> (pair index, first valid snapshot)
+        self.seq, self.pending, self.done = 0, None, False
+
+    def step(self, first=None):
+        ctx, eng = self.ctx, self.eng
+        jobs = []
+        while self.free and not ctx.exhausted:
+            nxt = first if first is not None else ctx.next_prepared(self.stream)
+            first = None
+            if nxt is None:
+                ctx.exhausted = True
+                break
+            i, p = nxt
+            slot = self.free.pop()
+            if slot in self.fin_done:
+                self.stream.wait_event(self.fin_done.pop(slot))   # the previous tenant's final warp read these params
+            jobs.append(p.load_job(slot))
+            self.active[slot] = (i, self.seq)            # snapshots >= seq see this pair in the slot
+        if jobs:
+            eng.load_jobs(jobs)
+        if not self.active and self.pending is None:
+            self.done = True
+            return
+        handle = None
+        if self.active:
+            eng.run_ticks(ctx.chunk)
+            handle = (eng.snapshot_async(), self.seq)
+            self.seq += 1
+        if self.pending is not None:
+            (h, hseq) = self.pending
+            states = eng.wait_snapshot(h)
+            done = []
+            for slot in list(self.active):
+                i, valid_from = self.active[slot]
+                st = states[slot]
+                if hseq < valid_from or st.level < ctx.m:
+                    continue
+                del self.active[slot]
+                ctx.preps[i].state = st
+                done.append((slot, ctx.preps[i]))
+                self.free.append(slot)
+            if done:
+                # the snapshot proves every tick that touched these slots has completed: the final warp
+                # needs no dependency on the lane's stream, only the slots' refill must wait for it
+                with torch.cuda.stream(ctx.fin_stream):
+                    outs = ctx.reg._finish(eng, done, freeze=True)
+                    ev = torch.cuda.Event()
+                    ev.record(ctx.fin_stream)
+                for (slot, p), out in zip(done, outs):
+                    self.fin_done[slot] = ev
+                    out.record_stream(ctx.main)
+                    p.result = out
+                    p.release()
+        self.pending = handle
+
+
 class Registration:
     def __init__(self, config):
         self.tgt_pcd = None
@@ -114,8 +189,10 @@ class Registration:
         todo = queue.Queue(maxsize=max(2 * slots * engines, 8))
         preps = [None] * len(pairs)
         dev = self._dev()
-        side = torch.cuda.Stream(dev) if prefetch else None
-        fin_stream = torch.cuda.Stream(dev)                      # final all-point warps overlap the ticking engines
+        # the streams live as long as the Registration: the caching allocator pools memory per stream, and fresh
+        # streams on every call made its reserved memory grow by ~0.7 GB per 512 pairs
+        side = self._stream("side", dev) if prefetch else None
+        fin_stream = self._stream("fin", dev)                    # final all-point warps overlap the ticking engines
 
         def produce():
             try:
@@ -167,82 +244,18 @@ class Registration:
 
         m = self.config.m
         main = torch.cuda.current_stream(dev)
-        shared = {"exhausted": False}
-
-        class Lane:
-            """One engine on one stream.  Pipelined control: the states of chunk k are read back while chunk k+1
-            runs, so the GPU never waits for the host; a slot that finishes in chunk k is refilled before chunk k+2.
-            Refills of one round go up in ONE launch (k_eng_load), the final all-point warps of the pairs that
-            finished in one chunk in ONE launch (k_pyramid_fwd) on the shared side stream."""
-
-            def __init__(lane, eng, stream):
-                lane.eng, lane.stream = eng, stream
-                lane.fin_done = {}                               # slot -> event: its parameters have been consumed
-                lane.active, lane.free = {}, list(range(eng.B))  # active: slot -> (pair index, first valid snapshot)
-                lane.seq, lane.pending, lane.done = 0, None, False
-
-            def step(lane, first=None):
-                eng = lane.eng
-                jobs = []
-                while lane.free and not shared["exhausted"]:
-                    nxt = first if first is not None else next_prepared(lane.stream)
-                    first = None
-                    if nxt is None:
-                        shared["exhausted"] = True
-                        break
-                    i, p = nxt
-                    slot = lane.free.pop()
-                    if slot in lane.fin_done:
-                        lane.stream.wait_event(lane.fin_done.pop(slot))   # the previous tenant's final warp read these params
-                    jobs.append(p.load_job(slot))
-                    lane.active[slot] = (i, lane.seq)            # snapshots >= seq see this pair in the slot
-                if jobs:
-                    eng.load_jobs(jobs)
-                if not lane.active and lane.pending is None:
-                    lane.done = True
-                    return
-                handle = None
-                if lane.active:
-                    eng.run_ticks(chunk)
-                    handle = (eng.snapshot_async(), lane.seq)
-                    lane.seq += 1
-                if lane.pending is not None:
-                    (h, hseq) = lane.pending
-                    states = eng.wait_snapshot(h)
-                    done = []
-                    for slot in list(lane.active):
-                        i, valid_from = lane.active[slot]
-                        st = states[slot]
-                        if hseq < valid_from or st.level < m:
-                            continue
-                        del lane.active[slot]
-                        preps[i].state = st
-                        done.append((slot, preps[i]))
-                        lane.free.append(slot)
-                    if done:
-                        # the snapshot proves every tick that touched these slots has completed: the final warp
-                        # needs no dependency on the lane's stream, only the slots' refill must wait for it
-                        with torch.cuda.stream(fin_stream):
-                            outs = self._finish(eng, done, freeze=True)
-                            ev = torch.cuda.Event()
-                            ev.record(fin_stream)
-                        for (slot, p), out in zip(done, outs):
-                            lane.fin_done[slot] = ev
-                            out.record_stream(main)
-                            p.result = out
-                            p.release()
-                lane.pending = handle
+        ctx = _BatchCtx(self, preps, next_prepared, fin_stream, main, chunk, m)
 
         first = next_prepared(main)
         B = min(slots, -(-len(pairs) // engines))
         lanes = []
         for e in range(engines):
-            stream = main if engines == 1 else torch.cuda.Stream(dev)
+            stream = main if engines == 1 else self._stream(("lane", e), dev)
             eng = self._engine(B, first[1], n_hint=self.config.samples + first[1].K, lane=e)
             with torch.cuda.stream(stream):
                 stream.wait_stream(main)
                 eng.park_all()
-            lanes.append(Lane(eng, stream))
+            lanes.append(_Lane(ctx, eng, stream))
         if engines > 1:                                          # the first pair was made visible to `main` only
             for t in first[1].tensors():
                 t.record_stream(lanes[0].stream)
@@ -258,9 +271,18 @@ class Registration:
             main.wait_stream(lane.stream)
         main.wait_stream(fin_stream)
         self.last_states = [p.state for p in preps]
-        return [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
+        results = [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
+        ctx.preps = ctx.next_prepared = None                     # nothing of this call stays reachable but the results
+        return results
 
     # ------------------------------------------------------------------ internals
+    def _stream(self, key, dev):
+        if not hasattr(self, "_streams"):
+            self._streams = {}
+        if key not in self._streams:
+            self._streams[key] = torch.cuda.Stream(dev)
+        return self._streams[key]
+
     def _dev(self):
         d = self.device
         if isinstance(d, int):
