@@ -440,16 +440,18 @@ struct BwdJob {
     float *dz_plane;        // [plane][128] gradient wrt the layer's pre-activation, rewritten in place for the layer below
     const float *h_plane;   // [plane][128] the layer's input activation (post-ReLU)
     int w_off, b_off;       // offsets of the layer's weight / bias inside params and inside the partial
+    int from_dO, wh_off, nh; // bwd2: recompute dz from dO through the nh head rows at params + wh_off (else: read dz_plane)
 };
 
 // NDP level: which slice of the flat parameter block the two generic backward stages work on
 __host__ __device__ inline void bwd_job_ndp_heads(BwdJob &job) {
     const ndp_layer_desc dd = {NDP_W, 2, 0, 0, 0, 0.f};
-    job.w_off = ndp_off_Wi(&dd, 3); job.b_off = 0;
+    job.w_off = ndp_off_Wi(&dd, 3); job.b_off = ndp_off_bi(&dd, 2);           // heads + the bias gradient of layer 2
 }
-__host__ __device__ inline void bwd_job_ndp_layer2(BwdJob &job) {
+__host__ __device__ inline void bwd_job_ndp_layer2(BwdJob &job, int nh) {
     const ndp_layer_desc dd = {NDP_W, 2, 0, 0, 0, 0.f};
     job.w_off = ndp_off_Wi(&dd, 2); job.b_off = ndp_off_bi(&dd, 2);
+    job.from_dO = 1; job.wh_off = ndp_off_Wi(&dd, 3); job.nh = nh;
 }
 
 __device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] global*/, float *dst /*LDS [64][LD]*/) {
@@ -494,7 +496,7 @@ __device__ __forceinline__ void store_dW(float *g, const f32x16 (&dW)[4], int wv
         for (int r = 0; r < 16; ++r) g[(32 * m + mfma_row(r, h)) * NDP_W + col] = dW[m][r];
 }
 
-// head stage of the backward: dz2 = (dO Wh) * [h2 > 0] written over the h2 plane ; dWh += dO^T h2 ; dbh
+// head stage of the backward: dWh += dO^T h2 ; dbh ; db2 = column sums of dz2 = (dO Wh) * [h2 > 0]
 // Light in registers (two MFMA accumulator pairs + 8 weight floats) -> many workgroups per CU.
 __device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
@@ -508,10 +510,10 @@ __device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, 
     f32x16 gWh;                                 // dWh[j][k]: rows j = mfma_row(r, h) (< 16 used), cols 32wv + l31
 #pragma unroll
     for (int r = 0; r < 16; ++r) gWh[r] = 0.f;
-    float gbh = 0.f;
+    float gbh = 0.f, gbz = 0.f;                 // gbz: column 32wv + l31 of the layer below, the rows this lane holds
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
-        float *plane2 = job.dz_plane + (size_t)base * NDP_W;
+        const float *plane2 = job.dz_plane + (size_t)base * NDP_W;      // still the activation h: read only
         {
             const float4 dv = reinterpret_cast<const float4 *>(job.dO + (size_t)base * NDP_NHMAX)[t];
             load_tile_to_lds(plane2, bufA);
@@ -535,12 +537,14 @@ __device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, 
                 const float A = l31 < NDP_NHMAX ? dOs[p * 17 + l31] : 0.f;
                 gWh = MFMA32(A, bufA[p * NDP_LD + 32 * wv + l31], gWh);
             }
+            // dz = (dO Wh) * [h > 0] is NOT stored: the layer below recomputes it from dO (16 MFMAs) instead of reading
+            // 512 B per point back from HBM; only its column sums (that layer's bias gradient) are taken here
             const int col = 32 * wv + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = mfma_row(r, h);
-                plane2[row * NDP_W + col] = bufA[row * NDP_LD + col] > 0.f ? a0[r] : 0.f;
-                plane2[(row + 32) * NDP_W + col] = bufA[(row + 32) * NDP_LD + col] > 0.f ? a1[r] : 0.f;
+                gbz += bufA[row * NDP_LD + col] > 0.f ? a0[r] : 0.f;
+                gbz += bufA[(row + 32) * NDP_LD + col] > 0.f ? a1[r] : 0.f;
             }
             if (t < NDP_NHMAX) {
                 for (int p = 0; p < 64; ++p) gbh += dOs[p * 17 + t];
@@ -555,6 +559,10 @@ __device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, 
         if (j < hc.nh) gwh[j * NDP_W + 32 * wv + l31] = gWh[r];
     }
     if (t < hc.nh) gwh[hc.nh * NDP_W + t] = gbh;
+    __syncthreads();
+    if (h == 1) bufA[32 * wv + l31] = gbz;
+    __syncthreads();
+    if (h == 0) job.gpart[job.b_off + 32 * wv + l31] = gbz + bufA[32 * wv + l31];
 }
 static constexpr int kSmemBwdHBytes = (64 * NDP_LD + 64 * 17) * 4;      // 38 KB
 
@@ -601,12 +609,38 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) dW2[m][r] = 0.f;
     float gb2[4] = {0.f, 0.f, 0.f, 0.f};
+    // first hidden layer below the heads (job.from_dO): its dz = (dO Wh) * [h > 0] is recomputed here from dO
+    // (K = 16: eight k-steps) over the activation tile, in place, instead of being written by bwdh and read back
+    float *dOs = sm + LB_DO;
+    float whb[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+        whb[ks] = (job.from_dO && (2 * ks + h) < job.nh) ? job.params[job.wh_off + (2 * ks + h) * NDP_W + 32 * wv + l31] : 0.f;
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
         float *plane2 = job.dz_plane + (size_t)base * NDP_W;
         PT_DECL;
-        load_tile_to_lds_colsum(plane2, bufB, gb2);                                // dz2 (+ db2)
-        load_tile_to_lds(job.h_plane + (size_t)base * NDP_W, bufA);                // h1
+        if (job.from_dO) {
+            const float4 dv = reinterpret_cast<const float4 *>(job.dO + (size_t)base * NDP_NHMAX)[t];
+            load_tile_to_lds(plane2, bufB);                                         // h2 (becomes dz2 below)
+            load_tile_to_lds(job.h_plane + (size_t)base * NDP_W, bufA);             // h1
+            float *dr = dOs + (t >> 2) * 17 + 4 * (t & 3);
+            dr[0] = dv.x; dr[1] = dv.y; dr[2] = dv.z; dr[3] = dv.w;
+            __syncthreads();
+            f32x16 z0, z1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { z0[r] = 0.f; z1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const float b0 = dOs[l31 * 17 + 2 * ks + h], b1 = dOs[(l31 + 32) * 17 + 2 * ks + h];
+                z0 = MFMA32(whb[ks], b0, z0);
+                z1 = MFMA32(whb[ks], b1, z1);
+            }
+            epilogue_mask(z0, z1, bufB, bufB, wv, l31, h);                          // own 32-column slab, in place
+        } else {
+            load_tile_to_lds_colsum(plane2, bufB, gb2);                             // dz (+ db of this layer)
+            load_tile_to_lds(job.h_plane + (size_t)base * NDP_W, bufA);             // h of the layer below
+        }
         PT(0);
         __syncthreads();
         PT(1);
@@ -633,7 +667,7 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
     }
     float *G = job.gpart;
     store_dW(G + job.w_off, dW2, wv, l31, h);
-    colsum_finish(gb2, sm + LB_BUFA, G + job.b_off);
+    if (!job.from_dO) colsum_finish(gb2, sm + LB_BUFA, G + job.b_off);              // (from_dO: bwdh wrote this bias gradient)
 }
 
 // hidden layer 1 and the input layer: dW1 += dz1^T h0 ; db1 ; dh0 = dz1 W1 ; dz0 = dh0 * [h0 > 0] ;
@@ -1278,6 +1312,7 @@ __device__ __forceinline__ bool eng_bwd_job(const ndp_engine &e, int parity, Bwd
     job.tile0 = blockIdx.x; job.tile_step = gridDim.x;
     job.dz_plane = job.act + 2 * (size_t)e.n_cap * NDP_W;
     job.h_plane = job.act + (size_t)e.n_cap * NDP_W;
+    job.from_dO = 0; job.wh_off = 0; job.nh = 0;
     return true;
 }
 
@@ -1295,7 +1330,7 @@ k_eng_bwd2(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
     if (!eng_bwd_job(e, parity, job, false)) return;
-    bwd_job_ndp_layer2(job);
+    bwd_job_ndp_layer2(job, make_head_cfg(desc_at_level(e.desc, e.state[(size_t)(parity ^ 1) * e.B + blockIdx.y].step_level)).nh);
     PT_INIT;
     bwd2_body(make_head_cfg(desc_at_level(e.desc, 0)), job, sm);
     PT_FLUSH(0);
@@ -1666,7 +1701,7 @@ extern "C" int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, in
     job.h_plane = act + (size_t)job.plane * NDP_W;
     bwd_job_ndp_heads(job);
     hipLaunchKernelGGL(k_level_bwdh, dim3(n_part), dim3(256), kSmemBwdHBytes, s, hc, job, p_stride);
-    bwd_job_ndp_layer2(job);
+    bwd_job_ndp_layer2(job, hc.nh);
     hipLaunchKernelGGL(k_level_bwd2, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
     hipLaunchKernelGGL(k_level_bwd1, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
     HIP_TRY(hipGetLastError(), "level backward launch");
@@ -1825,12 +1860,14 @@ extern "C" int ndp_nsfp_bwd(const float *params, const float *x, int n, float *a
     hipLaunchKernelGGL(k_nsfp_pack_g, dim3((job.plane + 255) / 256), dim3(256), 0, s, g, n, job.plane, dO_work);
     float *dz = act + 7 * psz;
     job.dz_plane = dz; job.h_plane = nullptr;
-    job.w_off = ndp_nsfp_off_W(NDP_NSFP_LAYERS); job.b_off = 0;
+    job.w_off = ndp_nsfp_off_W(NDP_NSFP_LAYERS); job.b_off = ndp_nsfp_off_b(NDP_NSFP_LAYERS - 1);   // + db8
     hipLaunchKernelGGL(k_level_bwdh, dim3(n_part), dim3(256), kSmemBwdHBytes, s, hc, job, p_stride);
     // hidden layers 8..2: dW_l += dz_l^T h_{l-1} ; db_l ; dz_{l-1} = (dz_l W_l) * [h_{l-1} > 0], in place in `dz`
+    // (layer 8 recomputes dz8 from dO through W9, the layers below read the dz the layer above left in the plane)
     for (int l = NDP_NSFP_LAYERS - 1; l >= 2; --l) {
         job.h_plane = act + (size_t)(l - 2) * psz;
         job.w_off = ndp_nsfp_off_W(l); job.b_off = ndp_nsfp_off_b(l);
+        job.from_dO = l == NDP_NSFP_LAYERS - 1; job.wh_off = ndp_nsfp_off_W(NDP_NSFP_LAYERS); job.nh = 3;
         hipLaunchKernelGGL(k_level_bwd2, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
     }
     hipLaunchKernelGGL(k_nsfp_in_bwd, dim3(n_part), dim3(256), 0, s, dz, x, n, job.n_tiles, grads_part, p_stride);
