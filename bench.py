@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # before HIP initialises: one hardware queue per busy stream (see the package __init__)
+
 import numpy as np
 import torch
 
