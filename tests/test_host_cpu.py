@@ -230,3 +230,14 @@ def test_4dmatch_npz_reader_builds_ground_truth_like_upstream(tmp_path):
     np.testing.assert_allclose(flow_gt.numpy(), want, rtol=0, atol=1e-6)
     assert overlap.sum().item() == 30 and overlap[:30].all() and not overlap[30:].any()
     assert src.shape == (n, 3) and tgt.shape == (m, 3)
+
+
+def test_package_import_reserves_hardware_queues_for_its_streams():
+    """Two engine streams on one ROCm hardware queue serialise: the package asks for 8 queues
+    unless the user set the variable."""
+    code = "import os; os.environ.pop('GPU_MAX_HW_QUEUES', None); import deformationpyramid_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "8", out.stderr[-500:]
+    code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '3'; import deformationpyramid_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert out.stdout.strip() == "3"
