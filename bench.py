@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 32 x slots)")
     ap.add_argument("--chunk", type=int, default=4, help="ticks between host polls")
     ap.add_argument("--engines", type=int, default=2, help="independent engines (HIP streams) per GPU, `slots` pairs each")
+    ap.add_argument("--fixed-work", action="store_true",
+                    help="SURVEY 8(d) config B: early stop off, 50 iterations x 9 levels = 450 Adam steps per pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -147,6 +149,8 @@ def main():
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // n_gpus)))   # host plumbing only; more threads hurt
 
     cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=local_rank)
+    if args.fixed_work:
+        cfg.iters, cfg.max_break_count = 50, 10 ** 9
     B = args.slots
     NP = args.pairs_per_step or 32 * B
     # inputs resident in HBM before the timed region
@@ -209,8 +213,11 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": "synthetic 8192-pt pair, NDP.yaml (SE3/axis-angle, m=9, samples=2000, iters<=500, "
-                               "early stop on), full register(): init + level/Adam loop + 8192-pt final warp",
+        "config": {"workload": ("synthetic 8192-pt pair, NDP.yaml with iters=50 and the early stop off (fixed work: 450 Adam "
+                                "iterations per pair), full register(): init + level/Adam loop + 8192-pt final warp"
+                                if args.fixed_work else
+                                "synthetic 8192-pt pair, NDP.yaml (SE3/axis-angle, m=9, samples=2000, iters<=500, "
+                                "early stop on), full register(): init + level/Adam loop + 8192-pt final warp"),
                    "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B * args.engines, "engines_per_gpu": args.engines, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective"},
         "ms_per_iter": 1e3 * elapsed * n_gpus / max(n_steps, 1.0),
         "adam_iters_per_pair": n_steps / n_pairs,
