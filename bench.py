@@ -120,7 +120,7 @@ def main():
     ap.add_argument("--slots", type=int, default=128, help="pairs resident per GPU (= pairs per step per GPU)")
     ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 32 x slots)")
     ap.add_argument("--chunk", type=int, default=4, help="ticks between host polls")
-    ap.add_argument("--engines", type=int, default=2, help="independent engines (HIP streams) per GPU, `slots` pairs each")
+    ap.add_argument("--engines", type=int, default=3, help="independent engines (HIP streams) per GPU, `slots` pairs each")
     ap.add_argument("--fixed-work", action="store_true",
                     help="SURVEY 8(d) config B: early stop off, 50 iterations x 9 levels = 450 Adam steps per pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
