@@ -28,7 +28,7 @@ def wrap(obj, name, label):
             key = label + ("[producer]" if threading.current_thread() is not threading.main_thread() else "")
             acc[key] += time.perf_counter() - t0; cnt[key] += 1
     setattr(obj, name, g)
-for n in ("load", "run_ticks", "snapshot_async", "wait_snapshot", "park"):
+for n in ("load_jobs", "run_ticks", "snapshot_async", "wait_snapshot"):
     wrap(E.BatchedEngine, n, "eng." + n)
 wrap(R.Registration, "_prepare", "prepare")
 wrap(R.Registration, "_finish", "finish")
