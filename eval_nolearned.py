@@ -13,6 +13,9 @@ then `compute_flow_metrics` averaged by `AverageMeter`, then the timer report.  
   (the 14 GB download is not available offline) `--synthetic N` seeded pairs stand in (SURVEY.md section 8d);
 * `--batched` registers all pairs through `Registration.register_batch` (many pairs resident on the
   GPU); without it the loop calls `register()` pair by pair exactly like upstream;
+* under `torchrun` (WORLD_SIZE > 1) the pairs of each benchmark are sharded over the ranks, one GPU per rank
+  (`parallel.shard_range`), and the per-metric sums are combined by ONE all-reduce (RCCL; `NDP_BENCH_BACKEND=gloo` for a
+  rehearsal on a box with one GPU) -- BASELINE.json config 3, "4DMatch-F full split batched across 8 GPUs";
 * `deformation_model: NDP` and the `NSFP` baseline (config/baselines/NSFP.yaml) are served; the other models are
   comparison baselines outside the scope.
 """
@@ -25,6 +28,7 @@ import torch
 
 from deformationpyramid_amd.config import load_config
 from deformationpyramid_amd.loss import compute_flow_metrics
+from deformationpyramid_amd.parallel import aggregate, shard_range
 from deformationpyramid_amd.registration import Registration
 from deformationpyramid_amd.synthetic import synthetic_pair
 from deformationpyramid_amd.utils import AverageMeter, Logger, Timers, setup_seed
@@ -81,8 +85,19 @@ def main():
     ap.add_argument("--slots", type=int, default=64)
     ap.add_argument("--synthetic", type=int, default=32, help="pairs to generate when the dataset is absent")
     args = ap.parse_args()
-    setup_seed(0)                                                           # once per process, as upstream
-    config = load_config(args.config, make_dirs=True)
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    backend = os.environ.get("NDP_BENCH_BACKEND", "nccl")
+    local_rank = 0 if backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    setup_seed(rank)                                                        # once per process, as upstream (seed 0 on one GPU)
+    config = load_config(args.config, make_dirs=rank == 0, device=local_rank)
     if config.deformation_model not in ("NDP", "NSFP"):
         raise KeyError(config.deformation_model)
     model = Registration(config)
@@ -95,8 +110,9 @@ def main():
         else:
             print(f"[{benchmark}] {root} not found: using {args.synthetic} synthetic pairs")
             data = SyntheticPairs(args.synthetic)
-        logger = Logger(os.path.join(config.snapshot_dir, benchmark + ".log"))
-        items = [data[i] for i in range(len(data))]
+        lo, hi = shard_range(len(data), rank, world)                        # this rank's pairs
+        items = [data[i] for i in range(lo, hi)]
+        n_total = len(data)
         if config.deformation_model == "NSFP":                              # eval_nolearned.py:97-110
             flows = []
             for src, tgt, _, _ in items:
@@ -127,14 +143,29 @@ def main():
                 meters = {k: AverageMeter() for k in info}
             for k, v in info.items():
                 meters[k].update(v)
-        message = f"{len(items)}/{len(items)}: " + "".join(f"{k}: {m.avg:.3f}\t" for k, m in meters.items())
-        logger.write(message + "\n")
-        print("score on ", benchmark, "\n", message)
+        if meters is None:                                                  # a rank without pairs still joins the all-reduce
+            z = compute_flow_metrics(torch.zeros(2, 3), torch.ones(2, 3), overlap=torch.tensor([True, False]))
+            meters = {k: AverageMeter() for k in z}
+        keys = list(meters.keys())
+        if world > 1:                                                       # one SUM all-reduce: per-metric sums + pair count
+            local = torch.tensor([m.sum for m in meters.values()] + [float(len(items))], dtype=torch.float64)
+            tot, _ = aggregate(local, 0.0, torch.device("cpu") if backend == "gloo" else torch.device("cuda", local_rank))
+            avgs = {k: float(tot[i] / tot[-1]) for i, k in enumerate(keys)}
+        else:
+            avgs = {k: m.avg for k, m in meters.items()}
+        if rank == 0:
+            message = f"{n_total}/{n_total}: " + "".join(f"{k}: {avgs[k]:.3f}\t" for k in keys)
+            Logger(os.path.join(config.snapshot_dir, benchmark + ".log")).write(message + "\n")
+            print("score on ", benchmark, "\n", message)
         if not os.path.isdir(root):
             break                                                           # one synthetic benchmark is enough
-    print("time cost average")
-    for line in timer.get_strings():
-        print(line)
+    if rank == 0:
+        print("time cost average")
+        for line in timer.get_strings():
+            print(line)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -227,3 +227,21 @@ def test_eval_drivers_run_end_to_end(tmp_path):
                          capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr[-2000:]
     assert re.search(r"4/4: full-epe: [0-9.]+", out.stdout), out.stdout[-800:]
+
+
+def test_eval_nolearned_shards_pairs_over_ranks(tmp_path):
+    """BASELINE config 3 in miniature: torchrun with two ranks (both on cuda:0, aggregate over gloo), 7 synthetic pairs
+    sharded 4 + 3, one all-reduce for the metric sums; rank 0 reports all 7."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NDP_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29519", os.path.join(root, "eval_nolearned.py"),
+                          "--config", os.path.join(root, "config", "NDP.yaml"), "--synthetic", "7", "--batched"],
+                         capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"7/7: full-epe: ([0-9.]+)", out.stdout)
+    assert m and 5.0 < float(m.group(1)) < 30.0, out.stdout[-800:]
+    assert out.stdout.count("score on") == 1                       # only rank 0 reports
