@@ -77,14 +77,9 @@ class SyntheticPairs:
         return synthetic_pair(i)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--config", type=str, default="config/NDP.yaml", help="Path to the config file.")
-    ap.add_argument("--visualize", action="store_true", help="(upstream flag; mayavi is out of scope here)")
-    ap.add_argument("--batched", action="store_true", help="register all pairs through register_batch")
-    ap.add_argument("--slots", type=int, default=64)
-    ap.add_argument("--synthetic", type=int, default=32, help="pairs to generate when the dataset is absent")
-    args = ap.parse_args()
+def dist_setup():
+    """-> (world, rank, local_rank, backend).  Under torchrun one process per GPU; NDP_BENCH_BACKEND=gloo keeps every
+    rank on cuda:0 and aggregates over gloo (rehearsal on a one-GPU box)."""
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     backend = os.environ.get("NDP_BENCH_BACKEND", "nccl")
     local_rank = 0 if backend == "gloo" else int(os.environ.get("LOCAL_RANK", "0"))
@@ -96,6 +91,32 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    return world, rank, local_rank, backend
+
+
+def reduce_meters(meters, n_items, world, local_rank, backend):
+    """Mean of the per-pair metrics over ALL ranks (what upstream's AverageMeter reports on one GPU): one SUM
+    all-reduce of the per-metric sums and the pair count."""
+    if meters is None:                                                      # a rank without pairs still joins the all-reduce
+        z = compute_flow_metrics(torch.zeros(2, 3), torch.ones(2, 3), overlap=torch.tensor([True, False]))
+        meters = {k: AverageMeter() for k in z}
+    keys = list(meters.keys())
+    if world > 1:
+        local = torch.tensor([m.sum for m in meters.values()] + [float(n_items)], dtype=torch.float64)
+        tot, _ = aggregate(local, 0.0, torch.device("cpu") if backend == "gloo" else torch.device("cuda", local_rank))
+        return keys, {k: float(tot[i] / tot[-1]) for i, k in enumerate(keys)}
+    return keys, {k: m.avg for k, m in meters.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, default="config/NDP.yaml", help="Path to the config file.")
+    ap.add_argument("--visualize", action="store_true", help="(upstream flag; mayavi is out of scope here)")
+    ap.add_argument("--batched", action="store_true", help="register all pairs through register_batch")
+    ap.add_argument("--slots", type=int, default=64)
+    ap.add_argument("--synthetic", type=int, default=32, help="pairs to generate when the dataset is absent")
+    args = ap.parse_args()
+    world, rank, local_rank, backend = dist_setup()
     setup_seed(rank)                                                        # once per process, as upstream (seed 0 on one GPU)
     config = load_config(args.config, make_dirs=rank == 0, device=local_rank)
     if config.deformation_model not in ("NDP", "NSFP"):
@@ -143,16 +164,7 @@ def main():
                 meters = {k: AverageMeter() for k in info}
             for k, v in info.items():
                 meters[k].update(v)
-        if meters is None:                                                  # a rank without pairs still joins the all-reduce
-            z = compute_flow_metrics(torch.zeros(2, 3), torch.ones(2, 3), overlap=torch.tensor([True, False]))
-            meters = {k: AverageMeter() for k in z}
-        keys = list(meters.keys())
-        if world > 1:                                                       # one SUM all-reduce: per-metric sums + pair count
-            local = torch.tensor([m.sum for m in meters.values()] + [float(len(items))], dtype=torch.float64)
-            tot, _ = aggregate(local, 0.0, torch.device("cpu") if backend == "gloo" else torch.device("cuda", local_rank))
-            avgs = {k: float(tot[i] / tot[-1]) for i, k in enumerate(keys)}
-        else:
-            avgs = {k: m.avg for k, m in meters.items()}
+        keys, avgs = reduce_meters(meters, len(items), world, local_rank, backend)
         if rank == 0:
             message = f"{n_total}/{n_total}: " + "".join(f"{k}: {avgs[k]:.3f}\t" for k in keys)
             Logger(os.path.join(config.snapshot_dir, benchmark + ".log")).write(message + "\n")

@@ -23,7 +23,8 @@ from deformationpyramid_amd.loss import compute_flow_metrics
 from deformationpyramid_amd.registration import Registration
 from deformationpyramid_amd.synthetic import synthetic_landmarks, synthetic_pair
 from deformationpyramid_amd.utils import AverageMeter, Logger, Timers, setup_seed
-from eval_nolearned import FourDMatchPairs
+from deformationpyramid_amd.parallel import shard_range
+from eval_nolearned import FourDMatchPairs, dist_setup, reduce_meters
 
 
 def main():
@@ -36,8 +37,9 @@ def main():
     ap.add_argument("--landmarks", type=str, default="", help="directory of precomputed <stem>.npz (ldmk_s, ldmk_t)")
     ap.add_argument("--K", type=int, default=500, help="synthetic landmarks per pair")
     args = ap.parse_args()
-    setup_seed(0)
-    config = load_config(args.config, make_dirs=True)
+    world, rank, local_rank, backend = dist_setup()              # torchrun: pairs sharded over ranks (BASELINE config 5)
+    setup_seed(rank)
+    config = load_config(args.config, make_dirs=rank == 0, device=local_rank)
     if config.deformation_model != "NDP":
         raise KeyError(config.deformation_model)
     model = Registration(config)
@@ -48,18 +50,20 @@ def main():
         items = []
         if os.path.isdir(root) and args.landmarks:
             data = FourDMatchPairs(config.data_root, benchmark)
-            for i in range(len(data)):
+            n_total = len(data)
+            for i in range(*shard_range(n_total, rank, world)):
                 src, tgt, flow_gt, overlap = data[i]
                 stem = os.path.splitext(os.path.basename(data.files[i]))[0]
                 lm = np.load(os.path.join(args.landmarks, stem + ".npz"))
                 ldmk = (torch.from_numpy(lm["ldmk_s"]).float(), torch.from_numpy(lm["ldmk_t"]).float())
                 items.append((src, tgt, flow_gt, overlap, ldmk))
         else:
-            print(f"[{benchmark}] dataset or --landmarks missing: {args.synthetic} synthetic pairs, K = {args.K} landmarks")
-            for p in range(args.synthetic):
+            if rank == 0:
+                print(f"[{benchmark}] dataset or --landmarks missing: {args.synthetic} synthetic pairs, K = {args.K} landmarks")
+            n_total = args.synthetic
+            for p in range(*shard_range(n_total, rank, world)):
                 src, tgt, flow_gt, overlap = synthetic_pair(p)
                 items.append((src, tgt, flow_gt, overlap, synthetic_landmarks(p, src, flow_gt, k=args.K)))
-        logger = Logger(os.path.join(config.snapshot_dir, benchmark + ".log"))
         if args.batched:
             timer.tic("registration")
             results = model.register_batch([(s, t, l) for s, t, _, _, l in items], slots=args.slots)
@@ -81,14 +85,20 @@ def main():
                 meters = {k: AverageMeter() for k in info}
             for k, v in info.items():
                 meters[k].update(v)
-        message = f"{len(items)}/{len(items)}: " + "".join(f"{k}: {m.avg:.3f}\t" for k, m in meters.items())
-        logger.write(message + "\n")
-        print("score on ", benchmark, "\n", message)
+        keys, avgs = reduce_meters(meters, len(items), world, local_rank, backend)
+        if rank == 0:
+            message = f"{n_total}/{n_total}: " + "".join(f"{k}: {avgs[k]:.3f}\t" for k in keys)
+            Logger(os.path.join(config.snapshot_dir, benchmark + ".log")).write(message + "\n")
+            print("score on ", benchmark, "\n", message)
         if not (os.path.isdir(root) and args.landmarks):
             break
-    print("time cost average")
-    for line in timer.get_strings():
-        print(line)
+    if rank == 0:
+        print("time cost average")
+        for line in timer.get_strings():
+            print(line)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -245,3 +245,19 @@ def test_eval_nolearned_shards_pairs_over_ranks(tmp_path):
     m = re.search(r"7/7: full-epe: ([0-9.]+)", out.stdout)
     assert m and 5.0 < float(m.group(1)) < 30.0, out.stdout[-800:]
     assert out.stdout.count("score on") == 1                       # only rank 0 reports
+
+
+def test_eval_supervised_shards_pairs_over_ranks(tmp_path):
+    """BASELINE config 5 in miniature: LNDP with (synthetic) precomputed landmarks, two ranks, one aggregate."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NDP_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29521", os.path.join(root, "eval_supervised.py"),
+                          "--config", os.path.join(root, "config", "LNDP.yaml"), "--synthetic", "5", "--batched"],
+                         capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    m = re.search(r"5/5: full-epe: ([0-9.]+)\s+full-AccS: ([0-9.]+)", out.stdout)
+    assert m and float(m.group(1)) < 1.5 and float(m.group(2)) > 99.0, out.stdout[-800:]
