@@ -832,7 +832,9 @@ extern "C" __global__ void k_grad_reduce(const float *gpart, int n_part, int p_s
 // tracked per 16-reference sub-chunk with v_min3 and the exact (lowest) index is recovered by re-scanning
 // the winning sub-chunk.  ~3.7 VALU instructions per distance instead of ~10.
 #define NN_STAGE 2048
+#ifndef NN_SUB
 #define NN_SUB 16
+#endif
 #define NN_QPB 512                    /* queries per workgroup (standalone operator: two per thread) */
 #ifndef NN_ENG_NQ
 #define NN_ENG_NQ 2                   /* engine: queries per thread (measured at 128 pairs: 2 -> 0.147 ms, 4 -> 0.157 ms, 8 -> 0.174 ms) */
