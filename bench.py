@@ -5,8 +5,11 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
            --master-port P bench.py --gpus N --steps K --warmup W
 
-One *step* registers `--pairs-per-step` (default 512 = 4 x `--slots`) synthetic 8192-point pairs per GPU,
-`--slots` (default 128) of them resident on the device at any time, with the shipped
+`python bench.py --gpus N` (no launcher, WORLD_SIZE unset) starts the N ranks itself: it re-executes this file under
+`torch.distributed.run --nproc-per-node N` on 127.0.0.1, one rank per GPU, backend nccl (= RCCL); rank 0 prints the line.
+
+One *step* registers `--pairs-per-step` (default 32 x `--slots`) synthetic 8192-point pairs per GPU,
+`--slots` (default 128) per engine of them resident on the device at any time, with the shipped
 NDP.yaml settings (SE3 / axis-angle, m = 9 levels, 2000 samples per cloud, lr 0.01, early stop on):
 per pair the full Registration.register() work -- pyramid init, centring, sampling, the level/Adam
 loop on the device, and the final warp of all 8192 source points.  The point clouds are resident in
@@ -112,6 +115,22 @@ def cpu_baseline(cfg, src, tgt):
             "ms_per_iter": 1e3 * dt / max(int(r["steps"]), 1)}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: become `torch.distributed.run --nproc-per-node N bench.py <same args>`
+    (one process per GPU, rendezvous on 127.0.0.1 at a free port) and exit with its status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL needs it on this driver)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, min(8, (os.cpu_count() or 8) // n))))
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -127,7 +146,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # NDP_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with ONE GPU (all ranks share cuda:0, the
@@ -135,7 +158,13 @@ def main():
     backend = os.environ.get("NDP_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         local_rank = 0
-    if world > 1:
+    elif world > 1 and torch.cuda.device_count() < world:
+        sys.exit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node has {torch.cuda.device_count()} "
+                 "(NDP_BENCH_BACKEND=gloo rehearses the multi-rank path with every rank on cuda:0)")
+    # NDP_BENCH_DIST=1 under a launcher with ONE rank still initialises the process group, so that the RCCL
+    # all-reduce of the aggregate runs on a 1-GPU box too (tests/test_bench_gpu.py)
+    use_dist = world > 1 or (os.environ.get("NDP_BENCH_DIST") == "1" and "RANK" in os.environ)
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -163,7 +192,7 @@ def main():
     torch.manual_seed(rank)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize(dev)
@@ -218,7 +247,10 @@ def main():
                                 if args.fixed_work else
                                 "synthetic 8192-pt pair, NDP.yaml (SE3/axis-angle, m=9, samples=2000, iters<=500, "
                                 "early stop on), full register(): init + level/Adam loop + 8192-pt final warp"),
-                   "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B * args.engines, "engines_per_gpu": args.engines, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective"},
+                   "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B * args.engines, "engines_per_gpu": args.engines, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective",
+                   "backend": ("none" if not use_dist else ("rccl" if backend == "nccl" else backend)),
+                   "seeds": "rank r registers synthetic_pair(r*pairs_per_step + i), i < pairs_per_step; torch.manual_seed(r) "
+                            "feeds the pyramid init and the sampling permutations"},
         "ms_per_iter": 1e3 * elapsed * n_gpus / max(n_steps, 1.0),
         "adam_iters_per_pair": n_steps / n_pairs,
         "loss_evals_per_pair": n_evals / n_pairs,
@@ -251,7 +283,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg, src, tgt)
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.destroy_process_group()
 

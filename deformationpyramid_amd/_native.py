@@ -76,28 +76,53 @@ MAX_WARP_JOBS = 32
 MAX_LOAD_JOBS = 16
 
 
+def source_id():
+    """Hex digest of the sources the library is built from (kernel file, device header, the two ABI headers) and of
+    the compile flags.  It is compiled into the library (-DNDP_BUILD_ID) and returned by ndp_build_id(): a library
+    whose id differs from the tree's was built from other sources -- lib() rebuilds it or refuses to load it, because
+    ndp_engine / ndp_load_job are passed BY VALUE into kernels and a stale layout would corrupt device memory."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, x)) for x in HEADERS]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(HIPCC_FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def _built_id(path):
+    """Build id of an existing library file (the tag string ndp_build_id() returns, found without loading it), or None."""
+    import re
+    try:
+        with open(path, "rb") as f:
+            hit = re.search(rb"NDP_BUILD_ID=([0-9a-f]{16})", f.read())
+        return hit.group(1).decode() if hit else None
+    except OSError:
+        return None
+
+
 def _stale():
-    if not os.path.exists(LIBPATH):
-        return True
-    t = os.path.getmtime(LIBPATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
-    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+    return not os.path.exists(LIBPATH) or _built_id(LIBPATH) != source_id()
 
 
 def build(force=False, verbose=False):
-    """hipcc --offload-arch=gfx950 ... -> deformationpyramid_amd/lib/libndp_hip.so (in-tree)."""
-    if not force and not _stale():
-        return LIBPATH
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        raise NdpError("hipcc not found and libndp_hip.so is missing or stale")
+    """hipcc --offload-arch=gfx950 ... -> deformationpyramid_amd/lib/libndp_hip.so (in-tree).  Serialised by a file
+    lock: N ranks that find a stale library build it once."""
+    import fcntl
     os.makedirs(LIBDIR, exist_ok=True)
-    tmp = f"{LIBPATH}.{os.getpid()}.tmp"              # build aside + atomic rename: concurrent ranks never see a torn file
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
-    os.replace(tmp, LIBPATH)
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIBPATH
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        if not os.path.exists(hipcc):
+            raise NdpError("hipcc not found and libndp_hip.so is missing or stale")
+        tmp = f"{LIBPATH}.{os.getpid()}.tmp"          # build aside + atomic rename: nobody ever sees a torn file
+        cmd = [hipcc] + HIPCC_FLAGS + [f'-DNDP_BUILD_ID="{source_id()}"', "-o", tmp] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIBPATH)
     return LIBPATH
 
 
@@ -124,24 +149,36 @@ _SIGS = {
     "ndp_engine_run_timed": [ctypes.POINTER(Engine), I, I, V, c_float_p],
     "ndp_engine_load": [ctypes.POINTER(Engine), I, ctypes.POINTER(LoadJob), I, V],
 }
-EXPORTS = ["ndp_version", "ndp_last_error"] + list(_SIGS)
+EXPORTS = ["ndp_version", "ndp_last_error", "ndp_build_id", "ndp_abi_sizes"] + list(_SIGS)
 
 
 def lib(allow_build=True):
     """Load the native library (building it first if the source is newer and hipcc exists)."""
     global _LIB
     if _LIB is None:
-        # Build only when the library is absent (or NDP_REBUILD=1 asks for a staleness check): file times do not
-        # survive every copy of the tree, and N ranks must never race to rebuild the same .so.
-        want = (not os.path.exists(LIBPATH)) or (os.environ.get("NDP_REBUILD") == "1" and _stale())
-        if allow_build and want and (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
-            build()
-        if not os.path.exists(LIBPATH):
-            raise NdpError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-        # NDP_HIP_LIB: developer override for timing-only experiment builds
-        L = ctypes.CDLL(os.environ.get("NDP_HIP_LIB", LIBPATH))
+        # The library carries the digest of the sources it was built from (ndp_build_id): an absent or stale library is
+        # rebuilt (under a file lock, so N ranks build once), and one that cannot be rebuilt is refused -- never loaded.
+        override = os.environ.get("NDP_HIP_LIB")     # developer override for timing-only experiment builds
+        if not override:
+            have_hipcc = bool(shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"))
+            if allow_build and have_hipcc and _stale():
+                build()
+            if not os.path.exists(LIBPATH):
+                raise NdpError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+            if _built_id(LIBPATH) != source_id():
+                raise NdpError(f"{LIBPATH} was built from other sources (build id {_built_id(LIBPATH)}, tree {source_id()}): "
+                               "run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = ctypes.CDLL(override or LIBPATH)
         L.ndp_version.restype = I
         L.ndp_last_error.restype = ctypes.c_char_p
+        L.ndp_build_id.restype = ctypes.c_char_p
+        L.ndp_abi_sizes.argtypes = [c_int_p]
+        L.ndp_abi_sizes.restype = I
+        sizes = (ctypes.c_int * 6)()
+        L.ndp_abi_sizes(sizes)
+        mine = [ctypes.sizeof(t) for t in (CLayerDesc, PairGeom, PairState, Engine, WarpJob, LoadJob)]
+        if list(sizes) != mine:
+            raise NdpError(f"struct layouts differ between {override or LIBPATH} {list(sizes)} and the ctypes mirror {mine}")
         for name, args in _SIGS.items():
             fn = getattr(L, name)
             fn.argtypes = args

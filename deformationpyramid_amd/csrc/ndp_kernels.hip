@@ -1646,8 +1646,19 @@ extern "C" int ndp_debug_phase_read(unsigned long long *out64, int reset) {
 }
 #endif
 
-extern "C" int ndp_version(void) { return 101; }
+#ifndef NDP_BUILD_ID
+#define NDP_BUILD_ID "unversioned"
+#endif
+extern "C" int ndp_version(void) { return 200; }
 extern "C" const char *ndp_last_error(void) { return g_err; }
+static const char k_build_tag[] = "NDP_BUILD_ID=" NDP_BUILD_ID;        // the loader finds this tag in the file without loading it
+extern "C" const char *ndp_build_id(void) { return k_build_tag + 13; }
+extern "C" int ndp_abi_sizes(int *out) {
+    if (!out) return fail(NDP_E_INVALID, "ndp_abi_sizes: null pointer");
+    out[0] = (int)sizeof(ndp_layer_desc); out[1] = (int)sizeof(ndp_pair_geom); out[2] = (int)sizeof(ndp_pair_state);
+    out[3] = (int)sizeof(ndp_engine);     out[4] = (int)sizeof(ndp_warp_job);  out[5] = (int)sizeof(ndp_load_job);
+    return 0;
+}
 
 extern "C" int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
                              const float *x, int n, float *x_out, float *act, float *heads, float *nonrig_out,

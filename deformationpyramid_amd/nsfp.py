@@ -119,7 +119,7 @@ def optimize_neural_SFlow(reg, visualize=False):
     params = model.flat
     m = torch.zeros(PARAM_COUNT, device=dev)
     v = torch.zeros(PARAM_COUNT, device=dev)
-    break_counter, loss_prev, steps = 0, 1e6, 0
+    break_counter, loss_prev, steps, L = 0, 1e6, 0, float("nan")   # iters == 0: the untrained warp, as upstream
     for i in range(config.iters):                                               # :511-529
         warped, act = nsfp_fwd(params, s_sample, save=True)
         loss, gx, _ = ops.chamfer_l1(warped, t_sample, 1e9)

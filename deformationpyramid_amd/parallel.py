@@ -17,7 +17,7 @@ def aggregate(values, elapsed, device):
     import torch.distributed as dist
     v = values.to(device=device, dtype=torch.float64).clone()
     t = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(v, op=dist.ReduceOp.SUM)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return v.cpu(), float(t.item())

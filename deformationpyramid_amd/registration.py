@@ -185,6 +185,13 @@ class Registration:
         pairs = list(pairs)
         if not pairs:
             return []
+        # one engine configuration serves the whole batch: capacities from the LARGEST landmark set (landmarks are known
+        # before any preparation), and the objective (w_cd / trunc_cd, registration.py:189-212) must be the same for all
+        ks = [int(item[2][0].shape[0]) if len(item) > 2 and item[2] is not None else 0 for item in pairs]
+        if min(ks) == 0 and max(ks) > 0:
+            raise ValueError("register_batch: pairs with and without landmarks use different objectives "
+                             "(registration.py:189-212); register them in separate batches")
+        k_max = max(ks)
         engines = max(1, min(int(engines), len(pairs)))
         todo = queue.Queue(maxsize=max(2 * slots * engines, 8))
         preps = [None] * len(pairs)
@@ -194,9 +201,23 @@ class Registration:
         side = self._stream("side", dev) if prefetch else None
         fin_stream = self._stream("fin", dev)                    # final all-point warps overlap the ticking engines
 
+        stop = threading.Event()
+
+        def put(item):
+            """Bounded put that gives up when the consumer has failed (so the thread never stays blocked)."""
+            while not stop.is_set():
+                try:
+                    todo.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
         def produce():
             try:
                 for i, item in enumerate(pairs):
+                    if stop.is_set():
+                        return
                     src, tgt = item[0], item[1]
                     ldmk = item[2] if len(item) > 2 else None
                     if isinstance(src, np.ndarray):
@@ -208,11 +229,13 @@ class Registration:
                             ev.record(side)
                     else:
                         p, ev = self._prepare(src.to(dev), tgt.to(dev), ldmk), None
-                    todo.put((i, p, ev))
-                todo.put(None)
+                    if not put((i, p, ev)):
+                        return
+                put(None)
             except BaseException as e:       # surface producer failures in the consumer
-                todo.put(e)
+                put(e)
 
+        th = None
         if prefetch:
             th = threading.Thread(target=produce, daemon=True)
             th.start()
@@ -246,27 +269,44 @@ class Registration:
         main = torch.cuda.current_stream(dev)
         ctx = _BatchCtx(self, preps, next_prepared, fin_stream, main, chunk, m)
 
-        first = next_prepared(main)
-        B = min(slots, -(-len(pairs) // engines))
-        lanes = []
-        for e in range(engines):
-            stream = main if engines == 1 else self._stream(("lane", e), dev)
-            eng = self._engine(B, first[1], n_hint=self.config.samples + first[1].K, lane=e)
-            with torch.cuda.stream(stream):
-                stream.wait_stream(main)
-                eng.park_all()
-            lanes.append(_Lane(ctx, eng, stream))
-        if engines > 1:                                          # the first pair was made visible to `main` only
-            for t in first[1].tensors():
-                t.record_stream(lanes[0].stream)
-            lanes[0].stream.wait_stream(main)
-        while not all(lane.done for lane in lanes):
-            for lane in lanes:
-                if lane.done:
-                    continue
-                with torch.cuda.stream(lane.stream):
-                    lane.step(first)
-                first = None
+        try:
+            first = next_prepared(main)
+            B = min(slots, -(-len(pairs) // engines))
+            lanes = []
+            for e in range(engines):
+                stream = main if engines == 1 else self._stream(("lane", e), dev)
+                eng = self._engine(B, first[1], n_hint=(self.config.samples if first[1].S else 0) + k_max, lane=e)
+                with torch.cuda.stream(stream):
+                    stream.wait_stream(main)
+                    eng.park_all()
+                lanes.append(_Lane(ctx, eng, stream))
+            if engines > 1:                                          # the first pair was made visible to `main` only
+                for t in first[1].tensors():
+                    t.record_stream(lanes[0].stream)
+                lanes[0].stream.wait_stream(main)
+            while not all(lane.done for lane in lanes):
+                for lane in lanes:
+                    if lane.done:
+                        continue
+                    with torch.cuda.stream(lane.stream):
+                        lane.step(first)
+                    first = None
+        except BaseException:
+            # a failing lane must not leave the producer blocked on the bounded queue, holding device tensors and
+            # pinned buffers: stop it, drain what it queued, join it, and let every stream finish what was enqueued
+            stop.set()
+            while True:
+                try:
+                    todo.get_nowait()
+                except queue.Empty:
+                    break
+            if th is not None:
+                th.join()
+            torch.cuda.synchronize(dev)
+            ctx.preps = ctx.next_prepared = None
+            raise
+        if th is not None:
+            th.join()
         for lane in lanes:
             main.wait_stream(lane.stream)
         main.wait_stream(fin_stream)

@@ -39,7 +39,9 @@ class FourDMatchPairs:
     with the ground truth built as in eval_nolearned.py:75-84."""
 
     def __init__(self, root, split, max_points=30000):
-        self.files = glob.glob(os.path.join(root, split, "*/*.npz"))      # raw glob order, as upstream
+        # upstream keeps the raw glob order (_4dmatch.py:47); sorted here so that every rank of a sharded run sees the
+        # same list (glob order is filesystem dependent) and the shards are a true partition
+        self.files = sorted(glob.glob(os.path.join(root, split, "*/*.npz")))
         self.max_points = max_points
 
     def __len__(self):

@@ -30,6 +30,11 @@ extern "C" {
 
 int ndp_version(void);                 /* 100*major + minor */
 const char *ndp_last_error(void);      /* text of the last non-zero return on this thread */
+/* Digest of the sources + flags the library was built from (the loader compares it with the tree and rebuilds or
+ * refuses a stale library), and sizeof of the six structs that cross the ABI by value, in declaration order:
+ * ndp_layer_desc, ndp_pair_geom, ndp_pair_state, ndp_engine, ndp_warp_job, ndp_load_job (the binding checks its mirror). */
+const char *ndp_build_id(void);
+int ndp_abi_sizes(int *out6);
 
 /* ------------------------------------------------------------------ single-pair operators */
 

@@ -1,0 +1,59 @@
+"""bench.py as the driver runs it: `python bench.py --gpus N` must start N ranks itself (row (e) of SURVEY section 8).
+
+On the one-GPU test box the two-rank case shares cuda:0 and aggregates over gloo (NDP_BENCH_BACKEND=gloo); the RCCL
+branch itself is exercised with one rank under a launcher (NDP_BENCH_DIST=1: process group "nccl", barrier and the
+all-reduce of the aggregate on the device).  The JSON lines are kept under gpurun_out/ (copied to profiles/ by hand).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "1", "--warmup", "0", "--pairs-per-step", "48", "--slots", "24", "--engines", "1",
+         "--no-cpu-baseline", "--no-roofline"]
+
+
+def _run(cmd, env=None, timeout=1500):
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                   # ONE line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def _keep(name, rec):
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, name), "w") as f:
+        json.dump(rec, f)
+
+
+@pytest.fixture(scope="module")
+def one_rank():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return _run([sys.executable, "bench.py", "--gpus", "1"] + SMALL)
+
+
+def test_bench_gpus_2_launches_two_ranks_itself(one_rank):
+    rec = _run([sys.executable, "bench.py", "--gpus", "2"] + SMALL, env={"NDP_BENCH_BACKEND": "gloo"})
+    _keep("bench_gpus2_gloo.json", rec)
+    assert rec["n_gpus"] == 2 and rec["config"]["backend"] == "gloo" and rec["scaling"] == "weak"
+    # both ranks share ONE GPU here: twice the pairs in about twice the time, so the whole-job rate stays put
+    assert 0.5 * one_rank["value"] < rec["value"] < 1.6 * one_rank["value"], (one_rank["value"], rec["value"])
+    # weak scaling: every rank registered its own pairs (distinct seeds), the aggregate counts all of them
+    assert abs(rec["ms_per_step"] * rec["value"] / 1e3 - 2 * 48) < 1e-6 * 96
+
+
+def test_bench_rccl_branch_runs_on_one_rank(one_rank):
+    rec = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                "127.0.0.1", "--master-port", "29533", "bench.py", "--gpus", "1"] + SMALL, env={"NDP_BENCH_DIST": "1"})
+    _keep("bench_rccl_1rank.json", rec)
+    assert rec["n_gpus"] == 1 and rec["config"]["backend"] == "rccl"
+    assert 0.6 * one_rank["value"] < rec["value"] < 1.6 * one_rank["value"]
+    assert rec["accuracy"].keys() == one_rank["accuracy"].keys()

@@ -241,3 +241,48 @@ def test_package_import_reserves_hardware_queues_for_its_streams():
     code = "import os; os.environ['GPU_MAX_HW_QUEUES'] = '3'; import deformationpyramid_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=300)
     assert out.stdout.strip() == "3"
+
+
+def test_bench_self_launch_builds_a_one_rank_per_gpu_command(monkeypatch):
+    """`python bench.py --gpus 4` with no launcher re-executes itself under torch.distributed.run."""
+    import subprocess
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 0
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2"])
+    with pytest.raises(SystemExit) as ex:
+        bench.self_launch(4)
+    assert ex.value.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "4", "--steps", "2"] and cmd[-5].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_register_batch_rejects_mixed_landmark_batches():
+    """Pairs with and without landmarks optimise different objectives (registration.py:189-212): one engine cannot
+    serve both, and silently running them with the first pair's weights would be wrong."""
+    from deformationpyramid_amd.config import load_config
+    from deformationpyramid_amd.registration import Registration
+    cfg = load_config(os.path.join(ROOT, "config", "LNDP.yaml"), device="cpu")
+    a, b = torch.zeros(10, 3), torch.zeros(12, 3)
+    with pytest.raises(ValueError, match="landmarks"):
+        Registration(cfg).register_batch([(a, b), (a, b, (a[:4], b[:4]))])
+
+
+def test_stale_library_is_detected_by_its_build_id(tmp_path):
+    """The library carries the digest of its sources; the loader finds it without loading the file."""
+    from deformationpyramid_amd import _native as N
+    assert N._built_id(N.LIBPATH) == N.source_id()
+    fake = tmp_path / "libfake.so"
+    fake.write_bytes(b"\x7fELF....NDP_BUILD_ID=0123456789abcdef\x00....")
+    assert N._built_id(str(fake)) == "0123456789abcdef" != N.source_id()
+    L = N.lib()
+    sizes = (ctypes.c_int * 6)()
+    assert L.ndp_abi_sizes(sizes) == 0 and sizes[3] == ctypes.sizeof(N.Engine) and sizes[2] == ctypes.sizeof(N.PairState)

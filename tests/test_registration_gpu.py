@@ -135,6 +135,29 @@ def test_register_batch_equals_sequential_register(cfg):
         assert (w - wa).abs().mean().item() < 5e-3
 
 
+def test_register_batch_sizes_engines_for_the_largest_landmark_set(cfg):
+    """Mixed landmark + Chamfer objective (w_cd > 0) with a growing K per pair: the engines are sized from max(K) over the
+    whole batch, not from the first pair; every pair equals its own sequential register() up to trajectory noise."""
+    from deformationpyramid_amd.config import Config, load_config
+    from deformationpyramid_amd.registration import Registration
+    from deformationpyramid_amd.synthetic import synthetic_landmarks, synthetic_pair
+    c = Config(load_config(os.path.join(ROOT, "config", "LNDP.yaml"), device=0), samples=200, m=3, iters=30, w_cd=0.5, trunc_cd=0.05)
+    pairs = []
+    for p, k in enumerate((20, 150, 400, 90)):                 # 200 + 20 rounds to 256; 200 + 400 needs 640
+        src, tgt, flow_gt, _ = synthetic_pair(40 + p, n_total=1200)
+        pairs.append((src, tgt, synthetic_landmarks(p, src, flow_gt, k=k)))
+    torch.manual_seed(5)
+    model = Registration(c)
+    out = model.register_batch(pairs, slots=2)
+    assert model._engines[0].n_cap >= 200 + 400
+    torch.manual_seed(5)
+    seq = Registration(c)
+    for (src, tgt, ldmk), (w, _) in zip(pairs, out):
+        seq.load_pcds(src, tgt, landmarks=ldmk)
+        ws, _, _ = seq.register()
+        assert torch.isfinite(w).all() and (w - ws).abs().mean().item() < 5e-3
+
+
 def test_autograd_wrappers_drive_a_caller_owned_loop(cfg):
     """shape_transfer.py style: the caller owns Adam, we supply warp() and the Chamfer loss."""
     from deformationpyramid_amd.loss import compute_truncated_chamfer_distance
