@@ -60,8 +60,8 @@ def kernel_profile(model, pairs, slots, n_ticks=24):
     ms = eng.run_ticks_timed(n_ticks)
     st = eng.read_states()
     active = sum(1 for s in st if s.level == 0)
-    names = ["k_eng_fwd", "k_eng_nn", "k_eng_loss", "k_eng_bwdh", "k_eng_bwd2", "k_eng_bwd1", "k_eng_update"]
-    return {k: v / n_ticks for k, v in zip(names, ms)}, eng, preps, active
+    from deformationpyramid_amd._native import TICK_KERNELS
+    return {k: v / n_ticks for k, v in zip(TICK_KERNELS, ms)}, eng, preps, active
 
 
 def pmc_traffic(kernel, pairs):
@@ -262,8 +262,8 @@ def main():
         S, T = preps[0].S, preps[0].T
         P = eng.P
         dom = max(prof, key=prof.get)
-        # backward split by layer: bwdh = heads (2*768 MAC), bwd2 = dW2 + dh1, bwd1 = dW1 + dh0 + dW0 (768 MAC)
-        flops = {"k_eng_fwd": FLOP_FWD_PT * S, "k_eng_bwdh": 2 * 1536 * S, "k_eng_bwd2": 2 * (2 * 16384) * S,
+        # backward split by layer: bwd2 = heads (dWh + dh2: 2*768 MAC) + dW2 + dh1, bwd1 = dW1 + dh0 + dW0 (768 MAC)
+        flops = {"k_eng_fwd": FLOP_FWD_PT * S, "k_eng_bwd2": 2 * (2 * 16384 + 1536) * S,
                  "k_eng_bwd1": 2 * (2 * 16384 + 768) * S, "k_eng_nn": FLOP_NN_PAIR * S * T,
                  "k_eng_update": 12 * P, "k_eng_loss": 4 * (S + T)}
         ach = flops[dom] * active / (prof[dom] * 1e-3) / 1e12

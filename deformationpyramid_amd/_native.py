@@ -73,6 +73,7 @@ class LoadJob(ctypes.Structure):
 
 
 MAX_WARP_JOBS = 32
+TICK_KERNELS = ("k_eng_fwd", "k_eng_nn", "k_eng_loss", "k_eng_bwd2", "k_eng_bwd1", "k_eng_update")   # one tick, launch order
 MAX_LOAD_JOBS = 16
 
 

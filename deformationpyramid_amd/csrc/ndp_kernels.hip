@@ -415,19 +415,35 @@ k_pyramid_fwd(ndp_layer_desc desc, int m, int k0, int p_stride, WarpJobs jobs) {
 // Level backward (autograd of nets.py:111-140 wrt the level's parameters), split by layer so that each
 // kernel keeps only ONE 128x128 weight slice + ONE 128x128 gradient accumulator in registers
 // (<= 256 VGPR+AGPR per lane => two workgroups per CU, whose load / VALU / MFMA phases overlap):
-//   bwd2: dO -> dz2 = (dO Wh) * [h2>0] ; dWh += dO^T h2 ; dW2 += dz2^T h1 ; dh1 = dz2 W2 ;
+//   bwd2: dO -> dz2 = (dO Wh) * [h2>0] ; dWh += dO^T h2 ; dbh ; dW2 += dz2^T h1 ; db2 ; dh1 = dz2 W2 ;
 //         dz1 = dh1 * [h1>0]  -> written over the (now dead) h2 plane of the activation store
-//   bwd1: dW1 += dz1^T h0 ; dh0 = dz1 W1 ; dz0 = dh0 * [h0>0] ; dW0 += dz0^T pe
+//   bwd1: dW1 += dz1^T h0 ; db1 ; dh0 = dz1 W1 ; dz0 = dh0 * [h0>0] ; [dW0 | db0] += dz0^T [pe | 1]
 // The per-point head backward (dO) is done before, one thread per point (k_head_bwd / k_eng_loss).
+//
+// LDS tiles of the backward are filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + 16 B x lane, so one
+// instruction lays down 1 KiB = two consecutive rows of the [64][128] tile, contiguously).  The image is therefore padded
+// per ROW PAIR, not per row:   float index of (row r, column c) = 260 (r >> 1) + 128 (r & 1) + c
+// (16 B of pad after every 1 KiB block).  Everything stays base + immediate (an XOR swizzle of the 16-byte chunks needs a
+// VGPR per address and spilled), the 16-lane groups of a ds_read_b128 over 16 rows hit 8 distinct 16-B slots (2-way, noise
+// next to 64-cycle MFMAs), and the b32 operand reads of one row are conflict-free.  No staging registers (the register-
+// staged loads had started to serialise -- one load in flight at a time -- once the head stage's accumulators moved into
+// bwd2 at the 256-register cap), no ds_write pass, and the global side is perfectly linear: lane l of block q reads
+// src + 1 KiB q + 16 B l.
 // ------------------------------------------------------------------------------------------------
+#define BP_PAIR 260                       /* floats per row pair: 2 x 128 + 4 pad */
+#define BP_TILE (32 * BP_PAIR)            /* floats per [64][128] tile image */
+#define NDP_PES 74                        /* posenc row stride in bwd1: banks 10 c + 4 lk never collide for c < 6, lk < 2 */
 enum : int {
     LB_BUFA = 0,
-    LB_BUFB = LB_BUFA + 64 * NDP_LD,
-    LB_DO = LB_BUFB + 64 * NDP_LD,        // [64][17] (stride 17: conflict-free MFMA A-operand reads)
-    LB_PE = LB_DO + 64 * 17,              // [6][64]
-    LB_TOTAL = LB_PE + 6 * 64
+    LB_BUFB = LB_BUFA + BP_TILE,
+    LB_DO = LB_BUFB + BP_TILE,            // [64][17] (stride 17: conflict-free MFMA operand reads over the points)
+    LB_PE = LB_DO + 64 * 17,              // [6][NDP_PES] posenc rows (bwd1)
+    LB_WH = LB_DO + 64 * 17,              // [NDP_WHROWS][128] head matrix, rows >= nh zero (bwd2; shares the posenc slot of bwd1)
+    LB_TOTAL = LB_WH + NDP_WHROWS * NDP_W
 };
-static constexpr int kSmemBwdBytes = LB_TOTAL * 4;       // 73.2 KB: two workgroups per CU
+static_assert(6 * NDP_PES <= NDP_WHROWS * NDP_W, "posenc rows must fit the shared slot");
+static constexpr int kSmemBwdBytes = LB_TOTAL * 4;       // 77.1 KB: two workgroups per CU
+static_assert(2 * kSmemBwdBytes <= 160 * 1024, "backward LDS carve must allow two workgroups per CU");
 
 struct BwdJob {
     const float *params;
@@ -436,7 +452,7 @@ struct BwdJob {
     const float *dO;        // [plane][16]
     float *gpart;           // this workgroup's partial [P]
     int n, plane, n_tiles, tile0, tile_step;
-    // layer-generic view used by bwdh / bwd2 (the NDP callers derive it from `act`; the NSFP chain walks its 8 planes):
+    // layer-generic view used by bwd2 (the NDP callers derive it from `act`; the NSFP chain walks its 8 planes):
     float *dz_plane;        // [plane][128] gradient wrt the layer's pre-activation, rewritten in place for the layer below
     const float *h_plane;   // [plane][128] the layer's input activation (post-ReLU)
     int w_off, b_off;       // offsets of the layer's weight / bias inside params and inside the partial
@@ -444,16 +460,13 @@ struct BwdJob {
 };
 
 // NDP level: which slice of the flat parameter block the two generic backward stages work on
-__host__ __device__ inline void bwd_job_ndp_heads(BwdJob &job) {
-    const ndp_layer_desc dd = {NDP_W, 2, 0, 0, 0, 0.f};
-    job.w_off = ndp_off_Wi(&dd, 3); job.b_off = ndp_off_bi(&dd, 2);           // heads + the bias gradient of layer 2
-}
 __host__ __device__ inline void bwd_job_ndp_layer2(BwdJob &job, int nh) {
     const ndp_layer_desc dd = {NDP_W, 2, 0, 0, 0, 0.f};
     job.w_off = ndp_off_Wi(&dd, 2); job.b_off = ndp_off_bi(&dd, 2);
     job.from_dO = 1; job.wh_off = ndp_off_Wi(&dd, 3); job.nh = nh;
 }
 
+// [64][128] tile: global -> padded LDS tile through registers (NSFP forward layers; the backward uses LDS-DMA)
 __device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] global*/, float *dst /*LDS [64][LD]*/) {
     const int t = threadIdx.x;
     float4 v[8];
@@ -466,26 +479,97 @@ __device__ __forceinline__ void load_tile_to_lds(const float *src /*[64][128] gl
     }
 }
 
-// dW += dz^T h over the tile's 64 points (the MFMA contraction index).  Accumulator block c holds the rows
-// o = 4*i + c (i = MFMA row 0..31): with that row permutation ONE ds_read_b128 of dz[p][4*l31 .. 4*l31+3] feeds the
-// A operands of all four blocks; the B operand is h[p][32wv + l31].  Operands of step ks+1 are fetched before the
-// MFMAs of step ks are issued (explicit software pipelining: the LDS latency used to be exposed every two MFMAs).
-// dW[mt] += dz^T h   (rows o = 32*mt.., cols k = 32wv + l31), contraction over the tile's 64 points.
+__device__ __forceinline__ int bp_row(int r) { return BP_PAIR * (r >> 1) + NDP_W * (r & 1); }
+
+// [64][128] tile: global -> LDS image by LDS-DMA, 8 x 1 KiB per wave (one row pair per instruction), asynchronous:
+// the caller waits with glds_wait() before the barrier that publishes the tile.
+__device__ __forceinline__ void glds_tile(const float *src /*global [64][128]*/, float *dst /*LDS image*/) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int q = 8 * wv + i;                                  // row pair
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void *)(src + 2 * NDP_W * q + 4 * lane),
+            (__attribute__((address_space(3))) void *)(dst + BP_PAIR * q), 16, 0, 0);
+    }
+}
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// tile_gemm_64x32 over an LDS-DMA tile image
+__device__ __forceinline__ void tile_gemm_64x32_sw(const float *in /*LDS image*/, const float (&w)[64],
+                                                   int l31, int h, f32x16 &acc0, f32x16 &acc1) {
+    const float *r0 = in + bp_row(l31) + 64 * h;
+    const float *r1 = r0 + 16 * BP_PAIR;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const float4 a0 = *reinterpret_cast<const float4 *>(r0 + 4 * i);
+        const float4 a1 = *reinterpret_cast<const float4 *>(r1 + 4 * i);
+        acc0 = MFMA32(w[4 * i], a0.x, acc0);     acc1 = MFMA32(w[4 * i], a1.x, acc1);
+        acc0 = MFMA32(w[4 * i + 1], a0.y, acc0); acc1 = MFMA32(w[4 * i + 1], a1.y, acc1);
+        acc0 = MFMA32(w[4 * i + 2], a0.z, acc0); acc1 = MFMA32(w[4 * i + 2], a1.z, acc1);
+        acc0 = MFMA32(w[4 * i + 3], a0.w, acc0); acc1 = MFMA32(w[4 * i + 3], a1.w, acc1);
+        if ((i & 3) == 3) asm volatile("" ::: "memory");
+    }
+}
+
+// backward epilogue of tile_gemm_64x32_sw: z = d * [hmask > 0] -> zout (same tile coordinates), b128 reads and writes
+__device__ __forceinline__ void epilogue_mask_sw(const f32x16 &d0, const f32x16 &d1, const float *hmask /*LDS*/,
+                                                 float *zout /*LDS*/, int wv, int l31, int h) {
+    const int off = bp_row(l31) + 32 * wv + 4 * h;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 m0 = *reinterpret_cast<const float4 *>(hmask + off + 8 * g);
+        const float4 m1 = *reinterpret_cast<const float4 *>(hmask + off + 16 * BP_PAIR + 8 * g);
+        *reinterpret_cast<float4 *>(zout + off + 8 * g) =
+            make_float4(m0.x > 0.f ? d0[4 * g] : 0.f, m0.y > 0.f ? d0[4 * g + 1] : 0.f,
+                        m0.z > 0.f ? d0[4 * g + 2] : 0.f, m0.w > 0.f ? d0[4 * g + 3] : 0.f);
+        *reinterpret_cast<float4 *>(zout + off + 16 * BP_PAIR + 8 * g) =
+            make_float4(m1.x > 0.f ? d1[4 * g] : 0.f, m1.y > 0.f ? d1[4 * g + 1] : 0.f,
+                        m1.z > 0.f ? d1[4 * g + 2] : 0.f, m1.w > 0.f ? d1[4 * g + 3] : 0.f);
+    }
+}
+
+// [64][128] tile: LDS image -> global, 8 float4 per thread, fully coalesced (thread t: rows (t >> 5) + 8i)
+__device__ __forceinline__ void store_tile_from_lds_sw(const float *src /*LDS image*/, float *dst /*global [64][128]*/) {
+    const int t = threadIdx.x;
+    const float *s0 = src + bp_row(t >> 5) + 4 * (t & 31);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        reinterpret_cast<float4 *>(dst)[t + 256 * i] = *reinterpret_cast<const float4 *>(s0 + 4 * BP_PAIR * i);
+}
+
+// dW[mt] += dz^T h   (rows o = 32*mt.., cols k = 32wv + l31), contraction over the tile's 64 points: A = dz[p][l31 + 32m],
+// B = h[p][32wv + l31], both conflict-free b32 reads of one row.
 // (A variant with the dW rows permuted so that one ds_read_b128 feeds all four A operands, software-pipelined by
 //  hand, measured SLOWER: bwd1 0.214 ms against 0.180 ms -- the compiler's own schedule of the b32 reads wins.)
-__device__ __forceinline__ void tile_outer_128x32(const float *dz /*LDS [64][LD]*/, const float *hin /*LDS [64][LD]*/,
-                                                  int wv, int l31, int h, f32x16 (&dW)[4]) {
+// COLSUM: the A operands are dz[p][l31 + 32m] for the 32 points of this lane's half -- adding them up as they pass gives
+// the column sums of dz (the layer's bias gradient) on the idle VALU: cs[m] += dz[32h .. 32h+31][l31 + 32m].
+template <bool COLSUM>
+__device__ __forceinline__ void tile_outer_128x32_sw(const float *dz /*LDS image*/, const float *hin /*LDS image*/,
+                                                     int wv, int l31, int h, f32x16 (&dW)[4], float (&cs)[4]) {
 #pragma unroll 2
     for (int ks = 0; ks < 32; ++ks) {
-        const int p = 32 * h + ks;
-        const float b = hin[p * NDP_LD + 32 * wv + l31];
-        const float *dr = dz + p * NDP_LD + l31;
+        const int ro = 16 * BP_PAIR * h + bp_row(ks);                // row p = 32h + ks
+        const float b = hin[ro + 32 * wv + l31];
+        const float *dr = dz + ro + l31;
         const float a0 = dr[0], a1 = dr[32], a2 = dr[64], a3 = dr[96];
         dW[0] = MFMA32(a0, b, dW[0]);
         dW[1] = MFMA32(a1, b, dW[1]);
         dW[2] = MFMA32(a2, b, dW[2]);
         dW[3] = MFMA32(a3, b, dW[3]);
+        if (COLSUM) { cs[0] += a0; cs[1] += a1; cs[2] += a2; cs[3] += a3; }
     }
+}
+// fold the two half-tile partials of tile_outer_128x32_sw<true> (taken from wave 0) -> out[128]   (sc: >= 256 floats of LDS)
+__device__ __forceinline__ void outer_colsum_finish(const float (&cs)[4], float *sc, float *out) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    if (t < 64) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sc[(t >> 5) * NDP_W + 32 * m + (t & 31)] = cs[m];
+    }
+    __syncthreads();
+    if (t < NDP_W) out[t] = sc[t] + sc[NDP_W + t];
 }
 
 __device__ __forceinline__ void store_dW(float *g, const f32x16 (&dW)[4], int wv, int l31, int h) {
@@ -496,110 +580,19 @@ __device__ __forceinline__ void store_dW(float *g, const f32x16 (&dW)[4], int wv
         for (int r = 0; r < 16; ++r) g[(32 * m + mfma_row(r, h)) * NDP_W + col] = dW[m][r];
 }
 
-// head stage of the backward: dWh += dO^T h2 ; dbh ; db2 = column sums of dz2 = (dO Wh) * [h2 > 0]
-// Light in registers (two MFMA accumulator pairs + 8 weight floats) -> many workgroups per CU.
-__device__ __forceinline__ void bwdh_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
-    float *bufA = sm, *dOs = sm + 64 * NDP_LD;
-    const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
-    const float *Wh = job.params + job.w_off;
-    // head matrix as an MFMA B operand: whb[ks] = Wh[j = 2ks + h][k = 32wv + l31], K = 16 head slots
-    float whb[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) whb[ks] = (2 * ks + h) < hc.nh ? Wh[(2 * ks + h) * NDP_W + 32 * wv + l31] : 0.f;
-    f32x16 gWh;                                 // dWh[j][k]: rows j = mfma_row(r, h) (< 16 used), cols 32wv + l31
-#pragma unroll
-    for (int r = 0; r < 16; ++r) gWh[r] = 0.f;
-    float gbh = 0.f, gbz = 0.f;                 // gbz: column 32wv + l31 of the layer below, the rows this lane holds
-    for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
-        const int base = tile * NDP_TILE;
-        const float *plane2 = job.dz_plane + (size_t)base * NDP_W;      // still the activation h: read only
-        {
-            const float4 dv = reinterpret_cast<const float4 *>(job.dO + (size_t)base * NDP_NHMAX)[t];
-            load_tile_to_lds(plane2, bufA);
-            float *dr = dOs + (t >> 2) * 17 + 4 * (t & 3);
-            dr[0] = dv.x; dr[1] = dv.y; dr[2] = dv.z; dr[3] = dv.w;
-        }
-        __syncthreads();
-        {
-            f32x16 a0, a1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
-                const float A0 = dOs[l31 * 17 + 2 * ks + h], A1 = dOs[(l31 + 32) * 17 + 2 * ks + h];
-                a0 = MFMA32(A0, whb[ks], a0);
-                a1 = MFMA32(A1, whb[ks], a1);
-            }
-#pragma unroll 4
-            for (int ks = 0; ks < 32; ++ks) {
-                const int p = 32 * h + ks;
-                const float A = l31 < NDP_NHMAX ? dOs[p * 17 + l31] : 0.f;
-                gWh = MFMA32(A, bufA[p * NDP_LD + 32 * wv + l31], gWh);
-            }
-            // dz = (dO Wh) * [h > 0] is NOT stored: the layer below recomputes it from dO (16 MFMAs) instead of reading
-            // 512 B per point back from HBM; only its column sums (that layer's bias gradient) are taken here
-            const int col = 32 * wv + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma_row(r, h);
-                gbz += bufA[row * NDP_LD + col] > 0.f ? a0[r] : 0.f;
-                gbz += bufA[(row + 32) * NDP_LD + col] > 0.f ? a1[r] : 0.f;
-            }
-            if (t < NDP_NHMAX) {
-                for (int p = 0; p < 64; ++p) gbh += dOs[p * 17 + t];
-            }
-        }
-        __syncthreads();
-    }
-    float *gwh = job.gpart + job.w_off;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int j = mfma_row(r, h);
-        if (j < hc.nh) gwh[j * NDP_W + 32 * wv + l31] = gWh[r];
-    }
-    if (t < hc.nh) gwh[hc.nh * NDP_W + t] = gbh;
-    __syncthreads();
-    if (h == 1) bufA[32 * wv + l31] = gbz;
-    __syncthreads();
-    if (h == 0) job.gpart[job.b_off + 32 * wv + l31] = gbz + bufA[32 * wv + l31];
-}
-static constexpr int kSmemBwdHBytes = (64 * NDP_LD + 64 * 17) * 4;      // 38 KB
+// point of (k-step ks, lane group lk) in the 16x16x4 MFMA stages that contract over a tile's 64 points: rows 4 apart
+// are 8 banks apart in the tile image, so the b32 B reads of a 32-lane group collide 2-way at worst
+__device__ __forceinline__ int mfma16_point(int ks, int lk) { return 16 * (ks >> 2) + 4 * lk + (ks & 3); }
 
-// load_tile_to_lds plus the column sums of the tile (a bias gradient), which fall out of the registers that carry
-// the copy: thread t adds its 8 rows of columns 4(t&31)..+3 to cs[]; the 8 row groups are folded once, at the end
-// of the kernel (a per-tile LDS read-and-add loop for the same sums used to cost 10k cycles per tile).
-__device__ __forceinline__ void load_tile_to_lds_colsum(const float *src, float *dst, float (&cs)[4]) {
-    const int t = threadIdx.x;
-    float4 v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const float4 *>(src)[t + 256 * i];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int idx = t + 256 * i;
-        *reinterpret_cast<float4 *>(dst + (idx >> 5) * NDP_LD + 4 * (idx & 31)) = v[i];
-        cs[0] += v[i].x; cs[1] += v[i].y; cs[2] += v[i].z; cs[3] += v[i].w;
-    }
-}
-// fold the 8 row-group partials of load_tile_to_lds_colsum in group order -> out[128]   (sc: >= 1024 floats of LDS)
-__device__ __forceinline__ void colsum_finish(const float (&cs)[4], float *sc, float *out) {
-    const int t = threadIdx.x;
-    __syncthreads();
-    *reinterpret_cast<float4 *>(sc + (t >> 5) * NDP_W + 4 * (t & 31)) = make_float4(cs[0], cs[1], cs[2], cs[3]);
-    __syncthreads();
-    if (t < NDP_W) {
-        float s = sc[t];
-#pragma unroll
-        for (int g = 1; g < 8; ++g) s += sc[g * NDP_W + t];
-        out[t] = s;
-    }
-}
-
-// hidden layer 2: dW2 += dz2^T h1 ; db2 ; dh1 = dz2 W2 ; dz1 = dh1 * [h1 > 0] written over dz2 (plane 2)
+// hidden layer l: dW_l += dz_l^T h_{l-1} ; db_l ; dh_{l-1} = dz_l W_l ; dz_{l-1} = dh_{l-1} * [h_{l-1} > 0] written over dz_l.
+// job.from_dO: l is the layer right below the heads.  Its dz = (dO Wh) * [h > 0] is computed here from dO (K = 16: eight
+// k-steps) over the activation tile, in place -- never stored to HBM -- and the head stage of the backward rides along:
+// dWh += dO^T h on the 16x16x4 MFMA (before h is overwritten), dbh from the registers that carry dO.
+// (Round 1 had a separate head kernel that read the whole h plane a second time.)
 __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, float *sm) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int l15 = lane & 15, lk = lane >> 4;
     float *bufA = sm + LB_BUFA, *bufB = sm + LB_BUFB;
-    const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
     const float *W2 = job.params + job.w_off;
     float w2t[64];
     load_w_bwd(W2, wv, l31, h, w2t);
@@ -608,38 +601,53 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dW2[m][r] = 0.f;
-    float gb2[4] = {0.f, 0.f, 0.f, 0.f};
-    // first hidden layer below the heads (job.from_dO): its dz = (dO Wh) * [h > 0] is recomputed here from dO
-    // (K = 16: eight k-steps) over the activation tile, in place, instead of being written by bwdh and read back
-    float *dOs = sm + LB_DO;
-    float whb[8];
+    float gb2[4] = {0.f, 0.f, 0.f, 0.f};            // db of this layer: column sums of dz, taken inside the dW outer product
+    float *dOs = sm + LB_DO, *whs = sm + LB_WH;
+    // head matrix (the MFMA A operand of dz = dO Wh) staged in LDS once: 8 registers through the GEMM phases were the
+    // difference between spilling and not
+    if (job.from_dO)
+        for (int i = t; i < NDP_WHROWS * NDP_W; i += 256) whs[i] = i < job.nh * NDP_W ? job.params[job.wh_off + i] : 0.f;
+    f32x4 gWha, gWhb;                               // dWh[j = 4lk + r][k = 32wv + l15 (a) / + 16 (b)]
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
-        whb[ks] = (job.from_dO && (2 * ks + h) < job.nh) ? job.params[job.wh_off + (2 * ks + h) * NDP_W + 32 * wv + l31] : 0.f;
+    for (int r = 0; r < 4; ++r) { gWha[r] = 0.f; gWhb[r] = 0.f; }
+    float4 gbh = make_float4(0.f, 0.f, 0.f, 0.f);   // partial sums of dO[.][4(t&3) ..]
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
         float *plane2 = job.dz_plane + (size_t)base * NDP_W;
         PT_DECL;
+        glds_tile(plane2, bufB);                                                    // h (becomes dz below), or dz
+        glds_tile(job.h_plane + (size_t)base * NDP_W, bufA);                        // h of the layer below
         if (job.from_dO) {
             const float4 dv = reinterpret_cast<const float4 *>(job.dO + (size_t)base * NDP_NHMAX)[t];
-            load_tile_to_lds(plane2, bufB);                                         // h2 (becomes dz2 below)
-            load_tile_to_lds(job.h_plane + (size_t)base * NDP_W, bufA);             // h1
             float *dr = dOs + (t >> 2) * 17 + 4 * (t & 3);
             dr[0] = dv.x; dr[1] = dv.y; dr[2] = dv.z; dr[3] = dv.w;
+            gbh.x += dv.x; gbh.y += dv.y; gbh.z += dv.z; gbh.w += dv.w;
+            glds_wait();
             __syncthreads();
+            {   // dWh += dO^T h over the tile's 64 points (16 k-steps x two 16-column blocks of this wave's slab)
+#pragma unroll 4
+                for (int ks = 0; ks < 16; ++ks) {
+                    const int p = mfma16_point(ks, lk);
+                    const float a = dOs[p * 17 + l15];
+                    const float *br = bufB + bp_row(p) + 32 * wv + l15;
+                    const float b0 = br[0], b1 = br[16];
+                    gWha = MFMA16(a, b0, gWha);
+                    gWhb = MFMA16(a, b1, gWhb);
+                }
+            }
             f32x16 z0, z1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { z0[r] = 0.f; z1[r] = 0.f; }
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) {
+            for (int ks = 0; ks < NDP_WHROWS / 2; ++ks) {                         // head rows j = 2ks + h < 12 (at most 11 exist)
+                const float a = whs[(2 * ks + h) * NDP_W + 32 * wv + l31];
                 const float b0 = dOs[l31 * 17 + 2 * ks + h], b1 = dOs[(l31 + 32) * 17 + 2 * ks + h];
-                z0 = MFMA32(whb[ks], b0, z0);
-                z1 = MFMA32(whb[ks], b1, z1);
+                z0 = MFMA32(a, b0, z0);
+                z1 = MFMA32(a, b1, z1);
             }
-            epilogue_mask(z0, z1, bufB, bufB, wv, l31, h);                          // own 32-column slab, in place
+            epilogue_mask_sw(z0, z1, bufB, bufB, wv, l31, h);                       // own 32-column slab, in place
         } else {
-            load_tile_to_lds_colsum(plane2, bufB, gb2);                             // dz (+ db of this layer)
-            load_tile_to_lds(job.h_plane + (size_t)base * NDP_W, bufA);             // h of the layer below
+            glds_wait();
         }
         PT(0);
         __syncthreads();
@@ -648,26 +656,46 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
             f32x16 d0, d1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
-            tile_outer_128x32(bufB, bufA, wv, l31, h, dW2);
-            tile_gemm_64x32(bufB, w2t, l31, h, d0, d1);
+            tile_outer_128x32_sw<true>(bufB, bufA, wv, l31, h, dW2, gb2);
+            tile_gemm_64x32_sw(bufB, w2t, l31, h, d0, d1);
             PT(2);
             __syncthreads();                       // every wave is done reading dz2
             PT(3);
             // dz1 goes through LDS so that HBM sees coalesced float4 rows (and the epilogue needs one base
             // address instead of 32 per-element addresses, which used to cost 58 spilled registers)
-            epilogue_mask(d0, d1, bufA, bufB, wv, l31, h);
+            epilogue_mask_sw(d0, d1, bufA, bufB, wv, l31, h);
         }
         PT(4);
         __syncthreads();
         PT(5);
-        store_tile_from_lds(bufB, plane2);
+        store_tile_from_lds_sw(bufB, plane2);
         PT(6);
         __syncthreads();
         PT(7);
     }
     float *G = job.gpart;
     store_dW(G + job.w_off, dW2, wv, l31, h);
-    if (!job.from_dO) colsum_finish(gb2, sm + LB_BUFA, G + job.b_off);              // (from_dO: bwdh wrote this bias gradient)
+    outer_colsum_finish(gb2, sm + LB_BUFA, G + job.b_off);
+    if (!job.from_dO) return;
+    // ---- head stage results: dWh rows j < nh, dbh
+    float *gwh = G + job.wh_off;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int j = 4 * lk + r;
+        if (j < job.nh) {
+            gwh[j * NDP_W + 32 * wv + l15] = gWha[r];
+            gwh[j * NDP_W + 32 * wv + 16 + l15] = gWhb[r];
+        }
+    }
+    float *sh = sm + LB_BUFB;                       // [256] float4: the dO row partials (the tiles are dead)
+    reinterpret_cast<float4 *>(sh)[t] = gbh;
+    __syncthreads();
+    if (t < job.nh) {
+        float s = sh[t];                                                          // thread 4q + (j >> 2), component j & 3
+#pragma unroll 8
+        for (int q = 1; q < 64; ++q) s += sh[4 * (4 * q + (t >> 2)) + (t & 3)];
+        gwh[job.nh * NDP_W + t] = s;
+    }
 }
 
 // hidden layer 1 and the input layer: dW1 += dz1^T h0 ; db1 ; dh0 = dz1 W1 ; dz0 = dh0 * [h0 > 0] ;
@@ -693,49 +721,46 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
         PT_DECL;
-        // ---- dz1 tile -> bufB (+ db1), h0 tile -> bufA, posenc -> pe
-        {
-            float4 pa = make_float4(0.f, 0.f, 0.f, 0.f), pb = pa;
-            if (t < 64) {
-                const float *hr = job.heads + (size_t)(base + t) * NDP_HROW;
-                pa = *reinterpret_cast<const float4 *>(hr + 16);
-                pb = *reinterpret_cast<const float4 *>(hr + 20);
-            }
-            load_tile_to_lds_colsum(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufB, gb1);
-            load_tile_to_lds(job.act + (size_t)base * NDP_W, bufA);
-            if (t < 64) {
-                pe[t] = pa.x; pe[64 + t] = pa.y; pe[128 + t] = pa.z; pe[192 + t] = pa.w;
-                pe[256 + t] = pb.x; pe[320 + t] = pb.y;
-            }
+        // ---- dz1 tile -> bufB, h0 tile -> bufA (LDS-DMA), posenc -> pe
+        glds_tile(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufB);
+        glds_tile(job.act + (size_t)base * NDP_W, bufA);
+        if (t < 64) {
+            const float *hr = job.heads + (size_t)(base + t) * NDP_HROW;
+            const float4 pa = *reinterpret_cast<const float4 *>(hr + 16);
+            const float4 pb = *reinterpret_cast<const float4 *>(hr + 20);
+            pe[t] = pa.x; pe[NDP_PES + t] = pa.y; pe[2 * NDP_PES + t] = pa.z; pe[3 * NDP_PES + t] = pa.w;
+            pe[4 * NDP_PES + t] = pb.x; pe[5 * NDP_PES + t] = pb.y;
         }
+        glds_wait();
         PT(0);
         __syncthreads();
         PT(1);
-        // ---- dW1 += dz1^T h0 ; dh0 = dz1 W1
+        // ---- dW1 += dz1^T h0 (+ db1) ; dh0 = dz1 W1
         f32x16 d0, d1;
         {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { d0[r] = 0.f; d1[r] = 0.f; }
-            tile_outer_128x32(bufB, bufA, wv, l31, h, dW1);
-            tile_gemm_64x32(bufB, w1t, l31, h, d0, d1);
+            tile_outer_128x32_sw<true>(bufB, bufA, wv, l31, h, dW1, gb1);
+            tile_gemm_64x32_sw(bufB, w1t, l31, h, d0, d1);
         }
         PT(2);
         __syncthreads();
         PT(3);
         // ---- dz0 = dh0 * [h0 > 0] -> bufB
-        epilogue_mask(d0, d1, bufA, bufB, wv, l31, h);
+        epilogue_mask_sw(d0, d1, bufA, bufB, wv, l31, h);
         PT(4);
         __syncthreads();
         PT(5);
         // ---- [dW0 | db0]^T += [pe | 1]^T dz0 on the 16x16x4 MFMA: A[c][p] = pe[c][p] (c < 6), 1 (c = 6), B[p][o] = dz0[p][o]
         {
-            const float *ap = pe + (l15 < 6 ? l15 : 0) * 64 + lk;
-            const float *bp = bufB + lk * NDP_LD + 32 * wv + l15;
+            const float *ap = pe + (l15 < 6 ? l15 : 0) * NDP_PES;
 #pragma unroll 4
             for (int ks = 0; ks < 16; ++ks) {
-                float a = ap[4 * ks];
+                const int p = mfma16_point(ks, lk);
+                float a = ap[p];
                 if (l15 >= 6) a = l15 == 6 ? 1.0f : 0.f;
-                const float b0 = bp[4 * ks * NDP_LD], b1 = bp[4 * ks * NDP_LD + 16];
+                const float *br = bufB + bp_row(p) + 32 * wv + l15;
+                const float b0 = br[0], b1 = br[16];
                 gW0a = MFMA16(a, b0, gW0a);
                 gW0b = MFMA16(a, b1, gW0b);
             }
@@ -760,7 +785,7 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
             }
         }
     }
-    colsum_finish(gb1, sm + LB_BUFA, G + ndp_off_bi(&dd, 1));
+    outer_colsum_finish(gb1, sm + LB_BUFA, G + ndp_off_bi(&dd, 1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -781,15 +806,6 @@ k_level_bwd2(HeadCfg hc, BwdJob job, int p_stride) {
     job.tile_step = gridDim.x;
     job.gpart += (size_t)blockIdx.x * p_stride;
     bwd2_body(hc, job, sm);
-}
-
-extern "C" __global__ void __launch_bounds__(256, 4)
-k_level_bwdh(HeadCfg hc, BwdJob job, int p_stride) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    job.tile0 = blockIdx.x;
-    job.tile_step = gridDim.x;
-    job.gpart += (size_t)blockIdx.x * p_stride;
-    bwdh_body(hc, job, sm);
 }
 
 extern "C" __global__ void __launch_bounds__(256, 2)
@@ -1318,20 +1334,11 @@ __device__ __forceinline__ bool eng_bwd_job(const ndp_engine &e, int parity, Bwd
     return true;
 }
 
-extern "C" __global__ void __launch_bounds__(256, 4)
-k_eng_bwdh(ndp_engine e, int parity) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    BwdJob job;
-    if (!eng_bwd_job(e, parity, job, true)) return;
-    bwd_job_ndp_heads(job);
-    bwdh_body(make_head_cfg(desc_at_level(e.desc, e.state[(size_t)(parity ^ 1) * e.B + blockIdx.y].step_level)), job, sm);
-}
-
 extern "C" __global__ void __launch_bounds__(256, 2)
 k_eng_bwd2(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     BwdJob job;
-    if (!eng_bwd_job(e, parity, job, false)) return;
+    if (!eng_bwd_job(e, parity, job, true)) return;                 // first backward kernel of the tick: idle partials read as zero
     bwd_job_ndp_layer2(job, make_head_cfg(desc_at_level(e.desc, e.state[(size_t)(parity ^ 1) * e.B + blockIdx.y].step_level)).nh);
     PT_INIT;
     bwd2_body(make_head_cfg(desc_at_level(e.desc, 0)), job, sm);
@@ -1705,15 +1712,12 @@ extern "C" int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, in
         n_part = job.n_tiles;
     }
     if (int rc = set_smem((const void *)k_level_bwd2, kSmemBwdBytes)) return rc;
-    if (int rc = set_smem((const void *)k_level_bwdh, kSmemBwdHBytes)) return rc;
     if (int rc = set_smem((const void *)k_level_bwd1, kSmemBwdBytes)) return rc;
     const HeadCfg hc = make_head_cfg(*desc);
     hipLaunchKernelGGL(k_head_bwd, dim3((job.plane + 255) / 256), dim3(256), 0, s, hc, x, heads, g,
                        desc->nonrigidity ? g_nr : nullptr, n, job.plane, dO_work);
     job.dz_plane = act + 2 * (size_t)job.plane * NDP_W;
     job.h_plane = act + (size_t)job.plane * NDP_W;
-    bwd_job_ndp_heads(job);
-    hipLaunchKernelGGL(k_level_bwdh, dim3(n_part), dim3(256), kSmemBwdHBytes, s, hc, job, p_stride);
     bwd_job_ndp_layer2(job, hc.nh);
     hipLaunchKernelGGL(k_level_bwd2, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
     hipLaunchKernelGGL(k_level_bwd1, dim3(n_part), dim3(256), kSmemBwdBytes, s, hc, job, p_stride);
@@ -1866,15 +1870,12 @@ extern "C" int ndp_nsfp_bwd(const float *params, const float *x, int n, float *a
         n_part = job.n_tiles;
     }
     if (int rc = set_smem((const void *)k_level_bwd2, kSmemBwdBytes)) return rc;
-    if (int rc = set_smem((const void *)k_level_bwdh, kSmemBwdHBytes)) return rc;
-    // output layer = a 3-row head stage: dz8 = (g W9) * [h8 > 0] over plane 7 ; dW9 += g^T h8 ; db9
+    // output layer = a 3-row head stage folded into the layer-8 launch: dz8 = (g W9) * [h8 > 0] over plane 7 ; dW9 += g^T h8 ; db9
     ndp_layer_desc d3 = {NDP_W, 2, NDP_MOTION_SFLOW, NDP_ROT_AXIS_ANGLE, 0, 1.0f};
     const HeadCfg hc = make_head_cfg(d3);                        // nh = 3
     hipLaunchKernelGGL(k_nsfp_pack_g, dim3((job.plane + 255) / 256), dim3(256), 0, s, g, n, job.plane, dO_work);
     float *dz = act + 7 * psz;
-    job.dz_plane = dz; job.h_plane = nullptr;
-    job.w_off = ndp_nsfp_off_W(NDP_NSFP_LAYERS); job.b_off = ndp_nsfp_off_b(NDP_NSFP_LAYERS - 1);   // + db8
-    hipLaunchKernelGGL(k_level_bwdh, dim3(n_part), dim3(256), kSmemBwdHBytes, s, hc, job, p_stride);
+    job.dz_plane = dz;
     // hidden layers 8..2: dW_l += dz_l^T h_{l-1} ; db_l ; dz_{l-1} = (dz_l W_l) * [h_{l-1} > 0], in place in `dz`
     // (layer 8 recomputes dz8 from dO through W9, the layers below read the dz the layer above left in the plane)
     for (int l = NDP_NSFP_LAYERS - 1; l >= 2; --l) {
@@ -1932,7 +1933,6 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
         return fail(NDP_E_INVALID, "ndp_engine_run: null buffer");
     if (int rc = set_smem((const void *)k_eng_fwd, kSmemFwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
-    if (int rc = set_smem((const void *)k_eng_bwdh, kSmemBwdHBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const dim3 blk(256);
@@ -1945,7 +1945,6 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
         hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         if (e->w_cd != 0.f && e->d2x) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
         hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
-        hipLaunchKernelGGL(k_eng_bwdh, g_lvl, blk, kSmemBwdHBytes, s, *e, parity);
         hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
@@ -1955,14 +1954,13 @@ extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void 
 }
 
 // Profiling variant of ndp_engine_run: HIP events around every kernel of every tick, recorded on the
-// launch stream; ms_out[7] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwdh, k_eng_bwd2, k_eng_bwd1, k_eng_update.
+// launch stream; ms_out[NDP_TICK_KERNELS] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwd2, k_eng_bwd1, k_eng_update.
 // Synchronises the stream before returning.  Used by bench.py for the roofline figures only.
 extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out) {
     if (!e || !ms_out || n_ticks < 1 || n_ticks > 4096) return fail(NDP_E_INVALID, "ndp_engine_run_timed: bad arguments");
     if (int rc = check_desc(&e->desc)) return rc;
     if (int rc = set_smem((const void *)k_eng_fwd, kSmemFwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
-    if (int rc = set_smem((const void *)k_eng_bwdh, kSmemBwdHBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     hipStream_t s = (hipStream_t)stream;
     const dim3 blk(256);
@@ -1971,7 +1969,7 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const bool nn = e->w_cd != 0.f && e->d2x;
     const dim3 g_loss((e->n_cap + 255) / 256 + 1, e->B);   // + 1: the loss / decision workgroup
-    const int per = 8;
+    const int per = NDP_TICK_KERNELS + 1;
     hipEvent_t *ev = new hipEvent_t[(size_t)n_ticks * per];
     for (int i = 0; i < n_ticks * per; ++i) (void)hipEventCreate(&ev[i]);
     for (int k = 0; k < n_ticks; ++k) {
@@ -1984,20 +1982,18 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
         (void)hipEventRecord(q[2], s);
         hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         (void)hipEventRecord(q[3], s);
-        hipLaunchKernelGGL(k_eng_bwdh, g_lvl, blk, kSmemBwdHBytes, s, *e, parity);
-        (void)hipEventRecord(q[4], s);
         hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
-        (void)hipEventRecord(q[5], s);
+        (void)hipEventRecord(q[4], s);
         hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
-        (void)hipEventRecord(q[6], s);
+        (void)hipEventRecord(q[5], s);
         hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
-        (void)hipEventRecord(q[7], s);
+        (void)hipEventRecord(q[6], s);
     }
     hipError_t err = hipStreamSynchronize(s);
-    for (int j = 0; j < 7; ++j) ms_out[j] = 0.f;
+    for (int j = 0; j < NDP_TICK_KERNELS; ++j) ms_out[j] = 0.f;
     if (err == hipSuccess) {
         for (int k = 0; k < n_ticks; ++k)
-            for (int j = 0; j < 7; ++j) {
+            for (int j = 0; j < NDP_TICK_KERNELS; ++j) {
                 float ms = 0.f;
                 (void)hipEventElapsedTime(&ms, ev[(size_t)k * per + j], ev[(size_t)k * per + j + 1]);
                 ms_out[j] += ms;

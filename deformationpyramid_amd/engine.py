@@ -155,8 +155,8 @@ class BatchedEngine:
         self.tick += n_ticks
 
     def run_ticks_timed(self, n_ticks):
-        """-> per-kernel summed milliseconds [fwd, nn, loss, bwdh, bwd2, bwd1, update] (HIP events on the launch stream)."""
-        ms = (ctypes.c_float * 7)()
+        """-> per-kernel summed milliseconds, in N.TICK_KERNELS order (HIP events on the launch stream)."""
+        ms = (ctypes.c_float * len(N.TICK_KERNELS))()
         N.check(self.lib.ndp_engine_run_timed(ctypes.byref(self.c_engine), self.tick, int(n_ticks),
                                               N.stream_ptr(self.device), ms), "ndp_engine_run_timed")
         self.tick += n_ticks

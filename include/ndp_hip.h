@@ -207,10 +207,10 @@ typedef struct ndp_load_job {
 #define NDP_MAX_LOAD_JOBS 16
 int ndp_engine_load(const ndp_engine *e, int tick, const ndp_load_job *jobs, int n_jobs, void *stream);
 
-/* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[7] (HOST memory)
- * receives the summed durations of the forward, NN, loss/gradient, backward-heads, backward-2, backward-1 and
- * update kernels over the
- * n_ticks ticks.  Synchronises `stream`.  Measurement aid for bench.py (roofline), not a product path. */
+/* Same launches with HIP events around every kernel, recorded on `stream`; ms_out[NDP_TICK_KERNELS] (HOST memory)
+ * receives the summed durations of the forward, NN, loss/gradient, backward-2 (+ heads), backward-1 and update
+ * kernels over the n_ticks ticks.  Synchronises `stream`.  Measurement aid for bench.py (roofline), not a product path. */
+#define NDP_TICK_KERNELS 6
 int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out);
 
 #ifdef __cplusplus

@@ -45,7 +45,7 @@ names = {0: "bwd2 load+lds", 1: "bwd2 barrier", 2: "bwd2 mfma(outer+gemm)+db", 3
          29: "bwd1 barrier", 30: "bwd1 dW0 (mfma16)", 31: "bwd1 barrier",
          14: "fwd layer0", 15: "fwd barrier", 16: "fwd layer1+h0 store", 17: "fwd barrier", 18: "fwd layer2+h1 store",
          19: "fwd barrier", 23: "fwd h2 store", 20: "fwd heads (mfma16)", 21: "fwd barrier"}
-print("per-tick ms [fwd nn loss bwdh bwd2 bwd1 upd]:", [round(x / ticks, 4) for x in ms])
+print("per-tick ms [fwd nn loss bwd2 bwd1 upd]:", [round(x / ticks, 4) for x in ms])
 for grp, lo in (("bwd2", 0), ("fwd", 12), ("bwd1", 24)):
     tot = sum(buf[i] for i in range(lo, lo + 12))
     print(f"{grp}: {tot / tiles:.0f} cycles per tile (thread 0 wall)")

@@ -24,4 +24,4 @@ for b, p in enumerate(preps):
 eng.run_ticks(4)
 torch.cuda.synchronize()
 ms = eng.run_ticks_timed(ticks)
-print("B", B, "G", eng.G, "per-tick ms [fwd nn loss bwdh bwd2 bwd1 upd]:", [round(x / ticks, 4) for x in ms], "sum", round(sum(ms) / ticks, 4))
+print("B", B, "G", eng.G, "per-tick ms [fwd nn loss bwd2 bwd1 upd]:", [round(x / ticks, 4) for x in ms], "sum", round(sum(ms) / ticks, 4))
