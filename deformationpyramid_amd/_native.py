@@ -57,7 +57,8 @@ class Engine(ctypes.Structure):
                 ("gpart", ctypes.c_void_p), ("adam_m", ctypes.c_void_p), ("adam_v", ctypes.c_void_p),
                 ("act", ctypes.c_void_p), ("heads", ctypes.c_void_p),
                 ("d2x", ctypes.c_void_p), ("idx_x", ctypes.c_void_p), ("d2y", ctypes.c_void_p),
-                ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p), ("dO", ctypes.c_void_p)]
+                ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p), ("dO", ctypes.c_void_p),
+                ("nn_row", ctypes.c_void_p)]
 
 
 class WarpJob(ctypes.Structure):
@@ -143,6 +144,7 @@ _SIGS = {
     "ndp_nsfp_fwd": [V, V, I, V, V, V, V],
     "ndp_nsfp_bwd": [V, V, I, V, V, V, V, I, I, V],
     "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],
+    "ndp_chamfer_nn_onepass": [V, I, V, I, V, V, V, V, V, V],
     "ndp_chamfer_l1_bwd": [V, I, V, I, F, V, V, V, V, V, V, V],
     "ndp_landmark_mse_fwd_bwd": [V, V, I, V, V, V],
     "ndp_adam_step": [V, V, V, V, I, F, F, F, F, F, F, V],
@@ -150,7 +152,7 @@ _SIGS = {
     "ndp_engine_run_timed": [ctypes.POINTER(Engine), I, I, V, c_float_p],
     "ndp_engine_load": [ctypes.POINTER(Engine), I, ctypes.POINTER(LoadJob), I, V],
 }
-EXPORTS = ["ndp_version", "ndp_last_error", "ndp_build_id", "ndp_abi_sizes"] + list(_SIGS)
+EXPORTS = ["ndp_version", "ndp_last_error", "ndp_build_id", "ndp_abi_sizes", "ndp_engine_nn_workspace"] + list(_SIGS)
 
 
 def lib(allow_build=True):
@@ -175,6 +177,8 @@ def lib(allow_build=True):
         L.ndp_build_id.restype = ctypes.c_char_p
         L.ndp_abi_sizes.argtypes = [c_int_p]
         L.ndp_abi_sizes.restype = I
+        L.ndp_engine_nn_workspace.argtypes = [I, I, ctypes.POINTER(ctypes.c_longlong)]
+        L.ndp_engine_nn_workspace.restype = I
         sizes = (ctypes.c_int * 6)()
         L.ndp_abi_sizes(sizes)
         mine = [ctypes.sizeof(t) for t in (CLayerDesc, PairGeom, PairState, Engine, WarpJob, LoadJob)]

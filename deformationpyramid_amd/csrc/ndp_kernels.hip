@@ -852,10 +852,6 @@ extern "C" __global__ void k_grad_reduce(const float *gpart, int n_part, int p_s
 #define NN_SUB 16
 #endif
 #define NN_QPB 512                    /* queries per workgroup (standalone operator: two per thread) */
-#ifndef NN_ENG_NQ
-#define NN_ENG_NQ 2                   /* engine: queries per thread (measured at 128 pairs: 2 -> 0.147 ms, 4 -> 0.157 ms, 8 -> 0.174 ms) */
-#endif
-#define NN_ENG_QPB (256 * NN_ENG_NQ)
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f32x2 pk_dist2(f32x2 X, f32x2 Y, f32x2 Z, f32x2 qx, f32x2 qy, f32x2 qz) {
@@ -1077,30 +1073,260 @@ k_eng_fwd(ndp_engine e, int parity) {
     PT_FLUSH(12);
 }
 
-// blockIdx.x < ceil(n_cap/512): source samples -> targets;  else targets -> source samples
+// ------------------------------------------------------------------------------------------------
+// One-pass exact 1-NN for the engine: every squared distance d2(x_i, y_j) is evaluated ONCE and serves both
+// directions (loss.py:177-178 calls knn_points twice; SURVEY 8(d) counts 8 S T FLOP for one pass).
+//   workgroup = ALL sources x NN1_YCH consecutive targets (SoA in LDS, broadcast ds_read_b128, packed fp32).  The
+//   sources are walked in rounds of 512: a thread keeps two of them in registers, wave w of round r owns the 128-source
+//   block 4r + w.
+//   ROW minimum (nearest target of a source): thread-private, tracked per 16-target sub-chunk, the winning sub-chunk
+//   re-scanned exactly at the end of the round; one partial {d2, idx} per (source, target chunk) goes to HBM and is
+//   folded by whoever reads it (first chunk wins ties = lowest index).
+//   COLUMN minimum (nearest source of a target): over the 128 sources of a wave it is a cross-lane reduction -- a
+//   transposed butterfly over the 16 column registers of a sub-chunk (v_permlane32_swap, v_permlane16_swap, DPP
+//   row_mirror / row_half_mirror / quad_perm: 35 instructions per 16 targets x 128 sources) -- into an LDS table
+//   [block][target]; when all rounds are done the workgroup folds the blocks in order (first block wins ties) and
+//   re-scans the winning block for the exact lowest index with the same arithmetic, from a copy of the sources in LDS.
+//   d2 and idx are bit-identical to the two-pass brute force (k_nn); nothing but the row partials needs a second look.
+// ------------------------------------------------------------------------------------------------
+#define NN1_XW 128                    /* sources per wave and round: granularity of the column table */
+#define NN1_XB (4 * NN1_XW)           /* sources per round */
+#define NN1_YCH 256                   /* targets per workgroup (512: 0.138 ms, 128: 0.137 + a slower row fold, 1024: 0.197) */
+#define NN1_XLD (NN1_XW + 1)          /* LDS stride of a 128-source block (the re-scan reads different blocks per lane) */
+
+// v_min_f32 / v_min3_f32 without the canonicalising v_max the compiler puts in front of every fminf operand it cannot
+// prove quiet (30 of them per 16-target sub-chunk): the instruction itself returns the other operand for a quiet NaN,
+// which is all the NaN padding needs
+__device__ __forceinline__ float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmin3(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float dpp_row_mirror(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x140, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float dpp_row_half_mirror(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), 0x141, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_quad(float v) {
+    return __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+
+// c[16]: per-lane values of 16 columns -> minimum over the 64 lanes of every column; lane L returns column L >> 2
+__device__ __forceinline__ float wave_colmin16(const float (&c)[16], int lane) {
+    float d[8], e[4], f[2];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {                  // lanes L and L ^ 32: lower half keeps column r, upper half column r + 8
+        const auto s = __builtin_amdgcn_permlane32_swap(__float_as_uint(c[r]), __float_as_uint(c[r + 8]), false, false);
+        d[r] = vmin(__uint_as_float(s[0]), __uint_as_float(s[1]));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                  // rows of 16 lanes: even rows keep column r, odd rows column r + 4
+        const auto s = __builtin_amdgcn_permlane16_swap(__float_as_uint(d[r]), __float_as_uint(d[r + 4]), false, false);
+        e[r] = vmin(__uint_as_float(s[0]), __uint_as_float(s[1]));
+    }
+    const bool b3 = lane & 8, b2 = lane & 4;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {                  // lane l and 15 - l of a row: bit 3 clear keeps r, set keeps r + 2
+        const float keep = b3 ? e[r + 2] : e[r], give = b3 ? e[r] : e[r + 2];
+        f[r] = vmin(keep, dpp_row_mirror(give));
+    }
+    const float keep = b2 ? f[1] : f[0], give = b2 ? f[0] : f[1];
+    float g = vmin(keep, dpp_row_half_mirror(give));           // lane l and 7 - l of a half row
+    g = vmin(g, dpp_quad<0xB1>(g));                            // the four lanes of a quad hold the same column:
+    g = vmin(g, dpp_quad<0x4E>(g));                            // fold them (quad_perm [1,0,3,2] then [2,3,0,1])
+    return g;
+}
+
+struct NnPart { float d2; int idx; };
+
+__host__ __device__ inline int nn1_row_chunks(int t_cap) { return (t_cap + NN1_YCH - 1) / NN1_YCH; }
+__host__ __device__ inline int nn1_col_blocks(int n_cap) { return (n_cap + NN1_XW - 1) / NN1_XW; }
+// dynamic LDS of the one-pass kernel (floats): target chunk, column table, re-scan results, (optionally) the sources
+__host__ __device__ inline int nn1_lds_floats(int n_cap, bool stage_x) {
+    const int nb = nn1_col_blocks(n_cap);
+    return 3 * NN1_YCH + nb * NN1_YCH + (stage_x ? 3 * nb * NN1_XLD : 0);
+}
+__host__ __device__ inline bool nn1_stage_x(int n_cap) { return nn1_lds_floats(n_cap, true) * 4 <= 80 * 1024; }
+
+// nearest target of source i from the row partials of the live target chunks (strict <: the first chunk keeps ties)
+__device__ __forceinline__ NnPart nn_row_fold(const NnPart *rowpart /*[chunks][n_cap]*/, int n_cap, int T, int i) {
+    NnPart r; r.d2 = INFINITY; r.idx = -1;
+    const int live = (T + NN1_YCH - 1) / NN1_YCH;
+    for (int ch = 0; ch < live; ++ch) {
+        const NnPart q = rowpart[(size_t)ch * n_cap + i];
+        if (q.d2 < r.d2) r = q;
+    }
+    return r;
+}
+
+// sources [S][3] at xs, targets [T][3] at ys; this workgroup: all sources x targets y0 .. y0 + NN1_YCH - 1.
+// rowpart: [n_cap] partials of THIS target chunk; d2y / idx_y: final results for the chunk's targets (idx_y = -1 for
+// y0 + j in [T, t_out)).
+template <bool STAGE_X>
+__device__ __forceinline__ void nn1_body(const float *xs, int S, const float *ys, int T, int y0, int t_out,
+                                         NnPart *rowpart, float *d2y, int *idx_y, float *sm) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nb = (S + NN1_XW - 1) / NN1_XW;      // live source blocks
+    float *lx = sm, *ly = sm + NN1_YCH, *lz = sm + 2 * NN1_YCH;
+    float *colp = sm + 3 * NN1_YCH;                // [nb][NN1_YCH]
+    float *sx = colp + nb * NN1_YCH;               // STAGE_X: [3][nb * NN1_XLD] sources, SoA per block
+    const float nanv = __builtin_nanf("");
+    const int cn = min(NN1_YCH, T - y0);           // >= 1
+    const int cpad = (cn + 15) & ~15;
+    for (int j = t; j < NN1_YCH; j += 256) {       // stage the target chunk (NaN padding: never wins a minimum nor an equality)
+        float v0 = nanv, v1 = nanv, v2 = nanv;
+        if (j < cn) { const float *rp = ys + 3 * (size_t)(y0 + j); v0 = rp[0]; v1 = rp[1]; v2 = rp[2]; }
+        lx[j] = v0; ly[j] = v1; lz[j] = v2;
+    }
+    if (STAGE_X) {
+        const int sn = nb * NN1_XLD;
+        for (int i = t; i < nb * NN1_XW; i += 256) {
+            float v0 = nanv, v1 = nanv, v2 = nanv;
+            if (i < S) { v0 = xs[3 * (size_t)i]; v1 = xs[3 * (size_t)i + 1]; v2 = xs[3 * (size_t)i + 2]; }
+            const int o = (i >> 7) * NN1_XLD + (i & 127);
+            sx[o] = v0; sx[sn + o] = v1; sx[2 * sn + o] = v2;
+        }
+    }
+    __syncthreads();
+    for (int xw = wv; xw < nb; xw += 4) {          // this wave's source blocks; no barrier inside
+        float qc[2][3];
+        f32x2 qx[2], qy[2], qz[2];
+        float best[2];
+        int sc_best[2];
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int i = xw * NN1_XW + 64 * w + lane;
+            qc[w][0] = qc[w][1] = qc[w][2] = nanv;                 // a missing source never wins a minimum
+            if (i < S) { qc[w][0] = xs[3 * (size_t)i]; qc[w][1] = xs[3 * (size_t)i + 1]; qc[w][2] = xs[3 * (size_t)i + 2]; }
+            qx[w] = f32x2{qc[w][0], qc[w][0]}; qy[w] = f32x2{qc[w][1], qc[w][1]}; qz[w] = f32x2{qc[w][2], qc[w][2]};
+            best[w] = INFINITY;
+            sc_best[w] = -1;
+        }
+        float *cp = colp + xw * NN1_YCH + (lane >> 2);
+        // (reading the NEXT sub-chunk's 12 broadcast ds_read_b128 ahead of the arithmetic measured slower: 0.141 vs 0.133 ms,
+        //  132 registers instead of 70)
+        for (int sc = 0; sc < cpad / 16; ++sc) {
+            float c[16], m[2] = {INFINITY, INFINITY};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int o = 16 * sc + 4 * u;
+                const float4 X = *reinterpret_cast<const float4 *>(lx + o);
+                const float4 Y = *reinterpret_cast<const float4 *>(ly + o);
+                const float4 Z = *reinterpret_cast<const float4 *>(lz + o);
+                const f32x2 X0 = {X.x, X.y}, X1 = {X.z, X.w}, Y0 = {Y.x, Y.y}, Y1 = {Y.z, Y.w}, Z0 = {Z.x, Z.y}, Z1 = {Z.z, Z.w};
+                const f32x2 a0 = pk_dist2(X0, Y0, Z0, qx[0], qy[0], qz[0]), a1 = pk_dist2(X1, Y1, Z1, qx[0], qy[0], qz[0]);
+                const f32x2 b0 = pk_dist2(X0, Y0, Z0, qx[1], qy[1], qz[1]), b1 = pk_dist2(X1, Y1, Z1, qx[1], qy[1], qz[1]);
+                m[0] = vmin3(m[0], a0.x, a0.y); m[0] = vmin3(m[0], a1.x, a1.y);
+                m[1] = vmin3(m[1], b0.x, b0.y); m[1] = vmin3(m[1], b1.x, b1.y);
+                c[4 * u] = vmin(a0.x, b0.x); c[4 * u + 1] = vmin(a0.y, b0.y);
+                c[4 * u + 2] = vmin(a1.x, b1.x); c[4 * u + 3] = vmin(a1.y, b1.y);
+            }
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+                if (m[w] < best[w]) { best[w] = m[w]; sc_best[w] = sc; }
+            const float g = wave_colmin16(c, lane);
+            if ((lane & 3) == 0) cp[16 * sc] = g;
+        }
+        // exact lowest index inside the winning sub-chunk (same arithmetic -> bitwise equality is safe)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int i = xw * NN1_XW + 64 * w + lane;
+            if (i >= S) continue;
+            int bi = -1;
+            if (sc_best[w] >= 0) {
+                const int j0 = 16 * sc_best[w];
+                for (int j = j0 + 15; j >= j0; --j) {
+                    const float dx = qc[w][0] - lx[j], dy = qc[w][1] - ly[j], dz = qc[w][2] - lz[j];
+                    const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    if (dd == best[w]) bi = y0 + j;               // descending j: the last hit is the lowest index
+                }
+            }
+            NnPart r; r.d2 = best[w]; r.idx = bi;
+            rowpart[i] = r;
+        }
+    }
+    __syncthreads();
+    // ---- columns: fold the blocks in order (the first block keeps ties), then the exact lowest index inside the winning
+    //      block, one thread per target, candidates from the LDS copy of the sources
+    for (int jj = t; jj < NN1_YCH; jj += 256) {
+        if (y0 + jj >= t_out) break;
+        if (jj >= cn) { idx_y[y0 + jj] = -1; continue; }
+        float cbest = INFINITY;
+        int blk = -1;
+        for (int k = 0; k < nb; ++k) {
+            const float v = colp[k * NN1_YCH + jj];
+            if (v < cbest) { cbest = v; blk = k; }
+        }
+        int r = -1;
+        if (blk >= 0) {
+            const float q0 = lx[jj], q1 = ly[jj], q2 = lz[jj];
+            const int k0 = blk * NN1_XW;
+            if (STAGE_X) {
+                const int sn = nb * NN1_XLD;
+                const float *bx = sx + blk * NN1_XLD;
+                for (int k = NN1_XW - 1; k >= 0; --k) {               // padding beyond S is NaN: never equal
+                    const float dx = bx[k] - q0, dy = bx[sn + k] - q1, dz = bx[2 * sn + k] - q2;
+                    const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    if (dd == cbest) r = k0 + k;                      // descending k: the last hit is the lowest index
+                }
+            } else {
+                for (int k = min(k0 + NN1_XW, S) - 1; k >= k0; --k) {
+                    const float dx = xs[3 * (size_t)k] - q0, dy = xs[3 * (size_t)k + 1] - q1, dz = xs[3 * (size_t)k + 2] - q2;
+                    const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+                    if (dd == cbest) r = k;
+                }
+            }
+        }
+        d2y[y0 + jj] = cbest;
+        idx_y[y0 + jj] = r;
+    }
+}
+
 extern "C" __global__ void __launch_bounds__(256)
-k_eng_nn(ndp_engine e, int parity) {
-    __shared__ __attribute__((aligned(16))) float sm[3 * NN_STAGE];
+k_eng_nn(ndp_engine e, int parity, int stage_x) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
     const int b = blockIdx.y;
     const ndp_pair_state st = e.state[parity * e.B + b];
     if (st.level >= e.m) return;
     const ndp_pair_geom gm = e.geom[b];
     if (gm.S == 0 || e.w_cd == 0.f) return;
+    const int y0 = blockIdx.x * NN1_YCH;
+    int *iy = e.idx_y + (size_t)b * e.t_cap;
+    if (y0 >= gm.T) {                               // keep the -1 padding beyond T
+        for (int j = y0 + threadIdx.x; j < min(y0 + NN1_YCH, e.t_cap); j += 256) iy[j] = -1;
+        return;
+    }
     const float *xw = e.pts + ((size_t)b * 2 + (st.cur ^ 1)) * e.n_cap * 3 + 3 * gm.K;
     const float *y = e.tgt + (size_t)b * e.t_cap * 3;
-    const int bx = (e.n_cap + NN_ENG_QPB - 1) / NN_ENG_QPB;
-    if ((int)blockIdx.x < bx) {
-        const int qb = blockIdx.x * NN_ENG_QPB;
-        if (qb >= gm.S) return;
-        nn_body<NN_ENG_NQ>(xw, gm.S, y, gm.T, e.d2x + (size_t)b * e.n_cap, e.idx_x + (size_t)b * e.n_cap, qb, sm);
-    } else {
-        const int qb = (blockIdx.x - bx) * NN_ENG_QPB;
-        float *d2y = e.d2y + (size_t)b * e.t_cap;
-        int *iy = e.idx_y + (size_t)b * e.t_cap;
-        if (qb < gm.T) nn_body<NN_ENG_NQ>(y, gm.T, xw, gm.S, d2y, iy, qb, sm);
-        for (int j = qb + threadIdx.x; j < min(qb + NN_ENG_QPB, e.t_cap); j += 256)
-            if (j >= gm.T) iy[j] = -1;             // keep the -1 padding the gradient scan relies on
-    }
+    NnPart *rowpart = reinterpret_cast<NnPart *>(e.nn_row) + ((size_t)b * nn1_row_chunks(e.t_cap) + blockIdx.x) * e.n_cap;
+    if (stage_x) nn1_body<true>(xw, gm.S, y, gm.T, y0, e.t_cap, rowpart, e.d2y + (size_t)b * e.t_cap, iy, sm);
+    else nn1_body<false>(xw, gm.S, y, gm.T, y0, e.t_cap, rowpart, e.d2y + (size_t)b * e.t_cap, iy, sm);
+}
+
+// the same kernel as a standalone operator on one pair, plus the fold of its row partials
+extern "C" __global__ void __launch_bounds__(256)
+k_nn1(const float *x, int S, const float *y, int T, int n_cap, float *ws_row, float *d2y, int *idx_y, int stage_x) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int y0 = blockIdx.x * NN1_YCH;
+    if (y0 >= T) return;
+    NnPart *rowpart = reinterpret_cast<NnPart *>(ws_row) + (size_t)blockIdx.x * n_cap;
+    if (stage_x) nn1_body<true>(x, S, y, T, y0, T, rowpart, d2y, idx_y, sm);
+    else nn1_body<false>(x, S, y, T, y0, T, rowpart, d2y, idx_y, sm);
+}
+extern "C" __global__ void __launch_bounds__(256)
+k_nn1_rows(int S, int T, int n_cap, const float *ws_row, float *d2x, int *idx_x) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S) return;
+    const NnPart r = nn_row_fold(reinterpret_cast<const NnPart *>(ws_row), n_cap, T, i);
+    d2x[i] = r.d2;
+    idx_x[i] = r.idx;
 }
 
 // Loss, early-stop decision and dL/dx' for every pair (one launch per tick).
@@ -1128,8 +1354,10 @@ k_eng_loss(ndp_engine e, int parity) {
     const float *x_out = e.pts + ((size_t)b * 2 + (st.cur ^ 1)) * e.n_cap * 3;
     const float *ldmk_t = e.ldmk_t + (size_t)b * e.n_cap * 3;
     const float *tgt = e.tgt + (size_t)b * e.t_cap * 3;
-    const float *d2x = e.d2x + (size_t)b * e.n_cap, *d2y = e.d2y + (size_t)b * e.t_cap;
-    const int *idx_x = e.idx_x + (size_t)b * e.n_cap, *idx_y = e.idx_y + (size_t)b * e.t_cap;
+    const float *d2y = e.d2y + (size_t)b * e.t_cap;
+    const int *idx_y = e.idx_y + (size_t)b * e.t_cap;
+    // nearest target of a source: folded here from the one-pass kernel's per-chunk partials (nn_row_fold)
+    const NnPart *rowpart = reinterpret_cast<const NnPart *>(e.nn_row) + (size_t)b * nn1_row_chunks(e.t_cap) * e.n_cap;
     const bool use_cd = gm.S > 0 && e.w_cd != 0.f;
     const HeadCfg hcl = make_head_cfg(desc_at_level(e.desc, st.level));
     const bool use_reg = e.w_reg > 0.f && hcl.nonrig;
@@ -1139,7 +1367,12 @@ k_eng_loss(ndp_engine e, int parity) {
         float loss = 0.f;
         if (gm.K > 0) loss = sq_sum(x_out, ldmk_t, gm.K, red) * (1.0f / (float)gm.K);
         if (use_cd) {
-            const float sx = l1_sum(d2x, gm.S, e.trunc, red);
+            float sx = 0.f;
+            for (int i = t; i < gm.S; i += 256) {
+                const float v = nn_row_fold(rowpart, e.n_cap, gm.T, i).d2;
+                sx += (v >= e.trunc) ? 0.f : sqrtf(v);
+            }
+            sx = block_sum_256(sx, red);
             const float sy = l1_sum(d2y, gm.T, e.trunc, red);
             const float lcd = sx / (float)gm.S + sy / (float)gm.T;
             loss = gm.K > 0 ? loss + e.w_cd * lcd : lcd;
@@ -1207,9 +1440,12 @@ k_eng_loss(ndp_engine e, int parity) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) g[a] = 2.0f * (w[a] - ldmk_t[3 * p + a]) * invK;
     } else if (p < n && use_cd) {
-        const float d2 = d2x[i_self];
+        const NnPart nx = nn_row_fold(rowpart, e.n_cap, gm.T, i_self);
+        const float d2 = nx.d2;
+        e.d2x[(size_t)b * e.n_cap + i_self] = nx.d2;                 // kept for inspection; nothing on the path reads them
+        e.idx_x[(size_t)b * e.n_cap + i_self] = nx.idx;
         if (!(d2 >= e.trunc)) {
-            const float *yy = tgt + 3 * idx_x[i_self];
+            const float *yy = tgt + 3 * nx.idx;
             const float inv = 1.0f / ((float)gm.S * sqrtf(d2));
 #pragma unroll
             for (int a = 0; a < 3; ++a) g[a] = (w[a] - yy[a]) * inv;
@@ -1922,76 +2158,82 @@ extern "C" int ndp_adam_step(float *params, const float *grads, float *m, float 
     return 0;
 }
 
-extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream) {
-    if (!e) return fail(NDP_E_INVALID, "null engine");
-    if (int rc = check_desc(&e->desc)) return rc;
-    if (e->B < 1 || e->G < 1 || e->m < 1 || e->m > NDP_MAX_LEVELS || e->n_cap % NDP_TILE || e->t_cap % NDP_TILE ||
-        e->P != ndp_param_count(&e->desc) || e->p_stride < e->P || (e->p_stride & 3))
-        return fail(NDP_E_INVALID, "ndp_engine_run: inconsistent engine descriptor");
-    if (!e->geom || !e->state || !e->pts || !e->params || !e->gpart || !e->adam_m || !e->adam_v || !e->act ||
-        !e->heads || !e->adam_tab || !e->dO)
-        return fail(NDP_E_INVALID, "ndp_engine_run: null buffer");
+// one tick = NDP_TICK_KERNELS launches; ev (optional): NDP_TICK_KERNELS + 1 events per tick recorded around them
+static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipStream_t s, hipEvent_t *ev) {
+    if (int rc = check_engine(e, "ndp_engine_run")) return rc;
+    const bool nn = e->w_cd != 0.f && e->t_cap > 0;
+    if (nn && (!e->nn_row || !e->d2x || !e->d2y || !e->idx_x || !e->idx_y || !e->tgt))
+        return fail(NDP_E_INVALID, "ndp_engine_run: Chamfer term without nearest-neighbour buffers");
+    const int stage_x = nn1_stage_x(e->n_cap) ? 1 : 0;
+    const int nn_lds = nn1_lds_floats(e->n_cap, stage_x) * 4;
+    if (nn_lds > 160 * 1024) return fail(NDP_E_UNSUPPORTED, "ndp_engine_run: n_cap too large for the one-pass nearest-neighbour kernel");
     if (int rc = set_smem((const void *)k_eng_fwd, kSmemFwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
-    hipStream_t s = (hipStream_t)stream;
+    if (nn) if (int rc = set_smem((const void *)k_eng_nn, nn_lds)) return rc;
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
-    const dim3 g_nn((e->n_cap + NN_ENG_QPB - 1) / NN_ENG_QPB + (e->t_cap + NN_ENG_QPB - 1) / NN_ENG_QPB, e->B);
+    const dim3 g_nn(nn1_row_chunks(e->t_cap), e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const dim3 g_loss((e->n_cap + 255) / 256 + 1, e->B);   // + 1: the loss / decision workgroup
     for (int k = 0; k < n_ticks; ++k) {
         const int parity = (tick0 + k) & 1;
-        hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
-        if (e->w_cd != 0.f && e->d2x) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
-        hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
-        hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
-        hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
-        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        hipEvent_t *q = ev ? ev + (size_t)k * (NDP_TICK_KERNELS + 1) : nullptr;
+        int j = 0;
+#define NDP_EV() do { if (q) (void)hipEventRecord(q[j++], s); } while (0)
+        NDP_EV(); hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
+        NDP_EV(); if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, nn_lds, s, *e, parity, stage_x);
+        NDP_EV(); hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
+        NDP_EV(); hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
+        NDP_EV(); hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
+        NDP_EV(); hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        NDP_EV();
+#undef NDP_EV
     }
     HIP_TRY(hipGetLastError(), "engine launch");
     return 0;
 }
 
-// Profiling variant of ndp_engine_run: HIP events around every kernel of every tick, recorded on the
-// launch stream; ms_out[NDP_TICK_KERNELS] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwd2, k_eng_bwd1, k_eng_update.
-// Synchronises the stream before returning.  Used by bench.py for the roofline figures only.
+extern "C" int ndp_engine_nn_workspace(int n_cap, int t_cap, long long *row_floats) {
+    if (n_cap < 0 || t_cap < 0 || n_cap % NDP_TILE || t_cap % NDP_TILE || !row_floats)
+        return fail(NDP_E_INVALID, "ndp_engine_nn_workspace: capacities must be multiples of 64");
+    *row_floats = 2LL * nn1_row_chunks(t_cap) * n_cap;          // NnPart = {float, int} per (target chunk, source)
+    return 0;
+}
+
+extern "C" int ndp_chamfer_nn_onepass(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y,
+                                      int *idx_y, float *ws_row, void *stream) {
+    if (S <= 0 || T <= 0 || !x || !y || !d2x || !idx_x || !d2y || !idx_y || !ws_row)
+        return fail(NDP_E_INVALID, "ndp_chamfer_nn_onepass: bad arguments");
+    const int n_cap = (S + NDP_TILE - 1) / NDP_TILE * NDP_TILE;
+    const int stage_x = nn1_stage_x(n_cap) ? 1 : 0;
+    const int lds = nn1_lds_floats(n_cap, stage_x) * 4;
+    if (lds > 160 * 1024) return fail(NDP_E_UNSUPPORTED, "ndp_chamfer_nn_onepass: S too large for the column table in LDS");
+    if (int rc = set_smem((const void *)k_nn1, lds)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_nn1, dim3((T + NN1_YCH - 1) / NN1_YCH), dim3(256), lds, s, x, S, y, T, n_cap, ws_row, d2y, idx_y, stage_x);
+    hipLaunchKernelGGL(k_nn1_rows, dim3((S + 255) / 256), dim3(256), 0, s, S, T, n_cap, ws_row, d2x, idx_x);
+    HIP_TRY(hipGetLastError(), "k_nn1 launch");
+    return 0;
+}
+
+extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream) {
+    return engine_launch_ticks(e, tick0, n_ticks, (hipStream_t)stream, nullptr);
+}
+
+// Profiling variant of ndp_engine_run: HIP events around every kernel of every tick, recorded on the launch stream;
+// ms_out[NDP_TICK_KERNELS] receives the SUMMED duration of k_eng_fwd, k_eng_nn, k_eng_loss, k_eng_bwd2, k_eng_bwd1,
+// k_eng_update.  Synchronises the stream before returning.  Used by bench.py for the roofline figures only.
 extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out) {
     if (!e || !ms_out || n_ticks < 1 || n_ticks > 4096) return fail(NDP_E_INVALID, "ndp_engine_run_timed: bad arguments");
-    if (int rc = check_desc(&e->desc)) return rc;
-    if (int rc = set_smem((const void *)k_eng_fwd, kSmemFwdBytes)) return rc;
-    if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
-    if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     hipStream_t s = (hipStream_t)stream;
-    const dim3 blk(256);
-    const dim3 g_lvl(e->G, e->B);
-    const dim3 g_nn((e->n_cap + NN_ENG_QPB - 1) / NN_ENG_QPB + (e->t_cap + NN_ENG_QPB - 1) / NN_ENG_QPB, e->B);
-    const dim3 g_upd((e->P + 255) / 256, e->B);
-    const bool nn = e->w_cd != 0.f && e->d2x;
-    const dim3 g_loss((e->n_cap + 255) / 256 + 1, e->B);   // + 1: the loss / decision workgroup
     const int per = NDP_TICK_KERNELS + 1;
     hipEvent_t *ev = new hipEvent_t[(size_t)n_ticks * per];
     for (int i = 0; i < n_ticks * per; ++i) (void)hipEventCreate(&ev[i]);
-    for (int k = 0; k < n_ticks; ++k) {
-        const int parity = (tick0 + k) & 1;
-        hipEvent_t *q = ev + (size_t)k * per;
-        (void)hipEventRecord(q[0], s);
-        hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
-        (void)hipEventRecord(q[1], s);
-        if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, 0, s, *e, parity);
-        (void)hipEventRecord(q[2], s);
-        hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
-        (void)hipEventRecord(q[3], s);
-        hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
-        (void)hipEventRecord(q[4], s);
-        hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
-        (void)hipEventRecord(q[5], s);
-        hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
-        (void)hipEventRecord(q[6], s);
-    }
+    int rc = engine_launch_ticks(e, tick0, n_ticks, s, ev);
     hipError_t err = hipStreamSynchronize(s);
     for (int j = 0; j < NDP_TICK_KERNELS; ++j) ms_out[j] = 0.f;
-    if (err == hipSuccess) {
+    if (rc == 0 && err == hipSuccess) {
         for (int k = 0; k < n_ticks; ++k)
             for (int j = 0; j < NDP_TICK_KERNELS; ++j) {
                 float ms = 0.f;
@@ -2001,7 +2243,7 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
     }
     for (int i = 0; i < n_ticks * per; ++i) (void)hipEventDestroy(ev[i]);
     delete[] ev;
+    if (rc) return rc;
     HIP_TRY(err, "ndp_engine_run_timed sync");
-    HIP_TRY(hipGetLastError(), "ndp_engine_run_timed launch");
     return 0;
 }

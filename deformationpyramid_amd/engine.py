@@ -65,6 +65,9 @@ class BatchedEngine:
         self.d2y = torch.zeros(B, self.t_cap, **f32)
         self.idx_x = torch.zeros(B, self.n_cap, device=d, dtype=torch.int32)
         self.idx_y = torch.full((B, self.t_cap), -1, device=d, dtype=torch.int32)
+        nr = ctypes.c_longlong()
+        N.check(self.lib.ndp_engine_nn_workspace(self.n_cap, self.t_cap, ctypes.byref(nr)), "ndp_engine_nn_workspace")
+        self.nn_row = torch.zeros(B, max(nr.value, 1), **f32)   # one-pass 1-NN row partials ({d2, idx} per source and target chunk)
         tab = np.zeros((cfg.iters + 1, 2), dtype=np.float32)
         for t in range(1, cfg.iters + 1):
             tab[t] = adam_scalars(t, cfg.lr)
@@ -90,7 +93,7 @@ class BatchedEngine:
         e.w_reg = c.w_reg if self.desc.nonrigidity else 0.0
         e.adam_w1, e.adam_b2, e.adam_w2, e.adam_eps = 1 - 0.9, 0.999, 1 - 0.999, 1e-8
         for name in ("geom", "state", "pts", "ldmk_t", "tgt", "params", "gpart", "adam_m", "adam_v", "act", "heads",
-                     "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "dO"):
+                     "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "dO", "nn_row"):
             setattr(e, name, getattr(self, name).data_ptr())
         self.c_engine = e
 

@@ -139,6 +139,20 @@ def chamfer_nn(x, y):
     return d2x, ix, d2y, iy
 
 
+def chamfer_nn_onepass(x, y):
+    """Same result as chamfer_nn from one pass over the S x T distances (the engine's per-tick kernels as an operator)."""
+    _chk(x, "x"); _chk(y, "y")
+    S, T = x.shape[0], y.shape[0]
+    nr = ctypes.c_longlong()
+    N.check(N.lib().ndp_engine_nn_workspace(cap(S), cap(T), ctypes.byref(nr)), "ndp_engine_nn_workspace")
+    ws_row = torch.empty(nr.value, device=x.device)
+    d2x = torch.empty(S, device=x.device); d2y = torch.empty(T, device=x.device)
+    ix = torch.empty(S, device=x.device, dtype=torch.int32); iy = torch.empty(T, device=x.device, dtype=torch.int32)
+    N.check(N.lib().ndp_chamfer_nn_onepass(_p(x), S, _p(y), T, _p(d2x), _p(ix), _p(d2y), _p(iy), _p(ws_row),
+                                           N.stream_ptr(x.device)), "ndp_chamfer_nn_onepass")
+    return d2x, ix, d2y, iy
+
+
 def chamfer_l1(x, y, trunc, nn=None, want_grad=True):
     """-> (loss [1], gx [S,3] | None, nn tuple)."""
     if nn is None:

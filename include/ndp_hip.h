@@ -110,6 +110,14 @@ int ndp_nsfp_bwd(const float *params, const float *x, int n, float *act, const f
 int ndp_chamfer_nn_fwd(const float *x, int S, const float *y, int T,
                        float *d2x, int *idx_x, float *d2y, int *idx_y, void *stream);
 
+/* The same result from ONE pass over the S x T squared distances (what the engine runs every tick): each distance is
+ * evaluated once and serves both directions -- row minima thread-private, column minima by a cross-lane butterfly per
+ * wave and an LDS table per workgroup, exact lowest indices by a re-scan of the winning 128-source block in LDS.
+ * Bit-identical to ndp_chamfer_nn_fwd.  ws_row: scratch of ndp_engine_nn_workspace(S rounded up to 64, T rounded up
+ * to 64) floats.                                                                                                   */
+int ndp_chamfer_nn_onepass(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y,
+                           int *idx_y, float *ws_row, void *stream);
+
 /* Truncated L1 Chamfer value and gradient from the NN result (loss.py:185-258 and its autograd):
  * loss[0] = sum_i sqrt(d2x_i)[d2x_i<trunc]/S + sum_j sqrt(d2y_j)[d2y_j<trunc]/T ;
  * gx [S][3] = dloss/dx (contributions of y_j -> x_i added in ascending j).                      */
@@ -182,7 +190,12 @@ typedef struct ndp_engine {
     float *d2y; int *idx_y;          /* [B][t_cap]                                              */
     const float *adam_tab;           /* [iters+1][2]: {neg_step, bc2_sqrt} for t = 1..iters     */
     float *dO;                       /* [B][n_cap][16] mlp_scale * dL/d(head outputs), this tick */
+    float *nn_row;                   /* one-pass 1-NN row partials, B x ndp_engine_nn_workspace() floats (NULL if w_cd == 0) */
 } ndp_engine;
+
+/* Floats PER PAIR of the row-partial buffer of the one-pass nearest-neighbour kernel ({d2, idx} per source and
+ * 128-target chunk).                                                                                             */
+int ndp_engine_nn_workspace(int n_cap, int t_cap, long long *row_floats);
 
 /* Launch n_ticks ticks starting at tick index tick0 (parity selects the state buffer read).
  * The caller initialises state[tick0 & 1] (level 0, iter 0, break_counter 0, loss_prev 1e6, cur 0).

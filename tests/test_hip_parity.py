@@ -520,6 +520,28 @@ def test_chamfer_nn_is_exact_on_adversarial_layouts(dev, name):
     np.testing.assert_array_equal(iy, r["idx_y"])
 
 
+@pytest.mark.parametrize("name", ["clusters", "far_queries", "plane", "line", "lattice_ties", "single_ref", "identical",
+                                  "skewed", "large", "ragged"])
+def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name):
+    """The engine's one-pass kernels (every distance evaluated once, column minima by cross-lane butterflies, second-stage
+    fold) must give the bits of the two-pass brute force: d2 and lowest index, both directions."""
+    from deformationpyramid_amd import ops
+    if name == "ragged":                         # sizes that end inside a wave / a 16-target sub-chunk / a 512-target chunk
+        g = torch.Generator().manual_seed(77)
+        x, y = torch.rand(1, 3, generator=g), torch.rand(1, 3, generator=g)
+        cases = [(x, y)] + [(torch.rand(s, 3, generator=g) - 0.5, torch.rand(t, 3, generator=g) - 0.5)
+                            for s, t in ((65, 17), (129, 513), (700, 1025), (2000, 1490), (513, 2047))]
+    else:
+        cases = [_nn_case(name)]
+    for x, y in cases:
+        r = O().chamfer(x.numpy(), y.numpy(), want_grad=False, nthreads=8)
+        d2x, ix, d2y, iy = [t.cpu().numpy() for t in ops.chamfer_nn_onepass(x.to(dev), y.to(dev))]
+        np.testing.assert_array_equal(d2x, r["d2x"])
+        np.testing.assert_array_equal(d2y, r["d2y"])
+        np.testing.assert_array_equal(ix, r["idx_x"])
+        np.testing.assert_array_equal(iy, r["idx_y"])
+
+
 def test_config3_stress_samples_8192(dev):
     """BASELINE config 3 (samples = 8192, Chamfer-bound): S = T = 8192 in the engine, two slots of different sizes."""
     eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=8192, T=8192, m=2, iters=2, early_stop=False,
