@@ -76,6 +76,37 @@ def pmc_traffic(kernel, pairs):
         return None
 
 
+def latency_profile(cfg, pairs, repeats=5):
+    """Batch 1 -- what the reference API is (one pair per register() call, /root/reference/eval_nolearned.py:89-93):
+    wall time of Registration.register() on single 8192-pt pairs, and the per-kernel split of one tick at B = 1."""
+    model = Registration(cfg)
+    torch.manual_seed(0)
+    dev = model._dev()
+    walls, iters = [], []
+    for r in range(repeats + 1):
+        src, tgt = pairs[r % len(pairs)]
+        model.load_pcds(src, tgt)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        model.register()
+        torch.cuda.synchronize(dev)
+        if r:                                          # the first call builds the engine
+            walls.append(time.perf_counter() - t0)
+            iters.append(model.last_state.total_steps)
+    prep = model._prepare(pairs[0][0], pairs[0][1], None)
+    eng = model._engine(1, prep)
+    eng.load_jobs([prep.load_job(0)])
+    eng.run_ticks(4)
+    n_ticks = 24
+    ms = eng.run_ticks_timed(n_ticks)
+    from deformationpyramid_amd._native import TICK_KERNELS
+    med = sorted(range(len(walls)), key=lambda i: walls[i])[len(walls) // 2]
+    return {"ms_per_pair": 1e3 * walls[med], "adam_iters": int(iters[med]), "ms_per_iter": 1e3 * walls[med] / max(iters[med], 1),
+            "ms_per_pair_all": [round(1e3 * w, 2) for w in walls], "workgroups_per_level_kernel": eng.G,
+            "kernels_ms_per_tick": {k: v / n_ticks for k, v in zip(TICK_KERNELS, ms)},
+            "tick_ms": sum(ms) / n_ticks}
+
+
 def cpu_baseline(cfg, src, tgt):
     """The oracle (oracle/ndp_oracle.c, a parity-pinned C port of the reference path) timed on this
     box's host cores on ONE full pair with the bench's settings."""
@@ -144,6 +175,7 @@ def main():
                     help="SURVEY 8(d) config B: early stop off, 50 iterations x 9 levels = 450 Adam steps per pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 register() latency measurement")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -278,6 +310,8 @@ def main():
             out["roofline"]["hbm_frac"] = out["roofline"]["hbm_tbps"] / 8.0
         out["kernels_ms_per_tick"] = prof
         out["tick"] = {"ms": tick_ms, "achieved_tflops": algorithmic_flops(S, T, P) * active / (tick_ms * 1e-3) / 1e12}
+    if rank == 0 and n_gpus == 1 and not args.no_latency:
+        out["latency"] = latency_profile(cfg, pairs)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         src, tgt = pairs[0]
         out["cpu_baseline"] = cpu_baseline(cfg, src, tgt)

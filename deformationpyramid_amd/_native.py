@@ -58,7 +58,7 @@ class Engine(ctypes.Structure):
                 ("act", ctypes.c_void_p), ("heads", ctypes.c_void_p),
                 ("d2x", ctypes.c_void_p), ("idx_x", ctypes.c_void_p), ("d2y", ctypes.c_void_p),
                 ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p), ("dO", ctypes.c_void_p),
-                ("nn_row", ctypes.c_void_p)]
+                ("nn_row", ctypes.c_void_p), ("nn_mode", ctypes.c_int), ("pad_i", ctypes.c_int)]
 
 
 class WarpJob(ctypes.Structure):

@@ -956,6 +956,88 @@ k_nn(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float
     else nn_body<2>(y, T, x, S, d2y, idx_y, (blockIdx.x - bx) * NN_QPB, sm);
 }
 
+// Latency shape of the exact 1-NN (few pairs resident: one pair must spread over the chip).  A workgroup owns 64
+// queries, one per lane; its four waves each scan a quarter of every 2048-reference stage (LDS, broadcast reads, the
+// same packed arithmetic and sub-chunk bookkeeping as nn_body), then the four candidates of a query are folded in
+// reference order (strict <: the earliest quarter keeps ties).  S/64 + T/64 workgroups per pair instead of S/512 + T/512.
+__device__ __forceinline__ void nn_lat_body(const float *q, int nq, const float *r, int nr, float *d2, int *idx,
+                                            int qbase, float *sm /*[3][NN_STAGE] + [4][64] + [4][64]*/) {
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    float *xs = sm, *ys = sm + NN_STAGE, *zs = sm + 2 * NN_STAGE;
+    float *cb = sm + 3 * NN_STAGE;
+    int *ci = reinterpret_cast<int *>(cb + 256);
+    const int i = qbase + lane;
+    float qc[3] = {0.f, 0.f, 0.f};
+    if (i < nq) { qc[0] = q[3 * (size_t)i]; qc[1] = q[3 * (size_t)i + 1]; qc[2] = q[3 * (size_t)i + 2]; }
+    const f32x2 qx = {qc[0], qc[0]}, qy = {qc[1], qc[1]}, qz = {qc[2], qc[2]};
+    float best = INFINITY;
+    int sc_best = -1;
+    for (int c0 = 0; c0 < nr; c0 += NN_STAGE) {
+        const int cn = min(NN_STAGE, nr - c0);
+        const int cpad = (cn + NN_SUB - 1) / NN_SUB * NN_SUB;
+        __syncthreads();
+        {
+            float v[NN_STAGE / 256][3];
+#pragma unroll
+            for (int k = 0; k < NN_STAGE / 256; ++k) {
+                const int j = t + 256 * k;
+                const float nanv = __builtin_nanf("");
+                v[k][0] = v[k][1] = v[k][2] = nanv;
+                if (j < cn) { const float *rp = r + 3 * (size_t)(c0 + j); v[k][0] = rp[0]; v[k][1] = rp[1]; v[k][2] = rp[2]; }
+            }
+#pragma unroll
+            for (int k = 0; k < NN_STAGE / 256; ++k) {
+                const int j = t + 256 * k;
+                if (j < cpad) { xs[j] = v[k][0]; ys[j] = v[k][1]; zs[j] = v[k][2]; }
+            }
+        }
+        __syncthreads();
+        const int nsub = cpad / NN_SUB, per = (nsub + 3) / 4;                 // sub-chunks of this stage, per wave
+        for (int sc = wv * per; sc < min(nsub, (wv + 1) * per); ++sc) {
+            float m = INFINITY;
+#pragma unroll
+            for (int u = 0; u < NN_SUB / 4; ++u) {
+                const int o = sc * NN_SUB + 4 * u;
+                const float4 X = *reinterpret_cast<const float4 *>(xs + o);
+                const float4 Y = *reinterpret_cast<const float4 *>(ys + o);
+                const float4 Z = *reinterpret_cast<const float4 *>(zs + o);
+                const f32x2 X0 = {X.x, X.y}, X1 = {X.z, X.w}, Y0 = {Y.x, Y.y}, Y1 = {Y.z, Y.w}, Z0 = {Z.x, Z.y}, Z1 = {Z.z, Z.w};
+                const f32x2 a0 = pk_dist2(X0, Y0, Z0, qx, qy, qz), a1 = pk_dist2(X1, Y1, Z1, qx, qy, qz);
+                m = fminf(fminf(m, a0.x), a0.y);
+                m = fminf(fminf(m, a1.x), a1.y);
+            }
+            if (m < best) { best = m; sc_best = c0 / NN_SUB + sc; }
+        }
+    }
+    int bi = -1;
+    if (sc_best >= 0 && i < nq) {
+        const int j0 = sc_best * NN_SUB, j1 = min(j0 + NN_SUB, nr);
+        for (int j = j1 - 1; j >= j0; --j) {
+            const float dx = qc[0] - r[3 * (size_t)j], dy = qc[1] - r[3 * (size_t)j + 1], dz = qc[2] - r[3 * (size_t)j + 2];
+            const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            if (dd == best) bi = j;
+        }
+    }
+    // The quarters of one stage are in reference order, but a later stage's quarter w precedes nothing of an earlier
+    // stage: a wave's running best is over ITS quarters of all stages, so ties across waves must be broken by index.
+    cb[64 * wv + lane] = best;
+    ci[64 * wv + lane] = bi;
+    __syncthreads();
+    if (wv == 0 && i < nq) {
+        float b = cb[lane];
+        int k = ci[lane];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            const float v = cb[64 * w + lane];
+            const int kv = ci[64 * w + lane];
+            if (v < b || (v == b && kv >= 0 && (k < 0 || kv < k))) { b = v; k = kv; }
+        }
+        d2[i] = b;
+        idx[i] = k;
+    }
+}
+static constexpr int kSmemNnLatBytes = (3 * NN_STAGE + 512) * 4;
+
 // sum_i sqrt(d2_i) [d2_i < trunc], deterministic block reduction (all 256 threads get the value)
 __device__ __forceinline__ float l1_sum(const float *d2, int n, float trunc, float *scratch) {
     float s = 0.f;
@@ -1157,6 +1239,7 @@ __host__ __device__ inline bool nn1_stage_x(int n_cap) { return nn1_lds_floats(n
 
 // nearest target of source i from the row partials of the live target chunks (strict <: the first chunk keeps ties)
 __device__ __forceinline__ NnPart nn_row_fold(const NnPart *rowpart /*[chunks][n_cap]*/, int n_cap, int T, int i) {
+    if (!rowpart) return NnPart{INFINITY, -1};
     NnPart r; r.d2 = INFINITY; r.idx = -1;
     const int live = (T + NN1_YCH - 1) / NN1_YCH;
     for (int ch = 0; ch < live; ++ch) {
@@ -1289,6 +1372,31 @@ __device__ __forceinline__ void nn1_body(const float *xs, int S, const float *ys
     }
 }
 
+// few pairs resident: blockIdx.x < ceil(n_cap/64): 64 source samples -> targets;  else 64 targets -> source samples.
+// Writes the final d2x / idx_x / d2y / idx_y (no partials): e.nn_mode = 1 tells the loss kernel to read them.
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_nn_lat(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int b = blockIdx.y;
+    const ndp_pair_state st = e.state[parity * e.B + b];
+    if (st.level >= e.m) return;
+    const ndp_pair_geom gm = e.geom[b];
+    if (gm.S == 0 || e.w_cd == 0.f) return;
+    const float *xw = e.pts + ((size_t)b * 2 + (st.cur ^ 1)) * e.n_cap * 3 + 3 * gm.K;
+    const float *y = e.tgt + (size_t)b * e.t_cap * 3;
+    const int bx = e.n_cap / 64;
+    if ((int)blockIdx.x < bx) {
+        const int qb = blockIdx.x * 64;
+        if (qb >= gm.S) return;
+        nn_lat_body(xw, gm.S, y, gm.T, e.d2x + (size_t)b * e.n_cap, e.idx_x + (size_t)b * e.n_cap, qb, sm);
+    } else {
+        const int qb = (blockIdx.x - bx) * 64;
+        int *iy = e.idx_y + (size_t)b * e.t_cap;
+        if (qb < gm.T) nn_lat_body(y, gm.T, xw, gm.S, e.d2y + (size_t)b * e.t_cap, iy, qb, sm);
+        if (threadIdx.x < 64 && qb + (int)threadIdx.x >= gm.T && qb + (int)threadIdx.x < e.t_cap) iy[qb + threadIdx.x] = -1;
+    }
+}
+
 extern "C" __global__ void __launch_bounds__(256)
 k_eng_nn(ndp_engine e, int parity, int stage_x) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1358,6 +1466,7 @@ k_eng_loss(ndp_engine e, int parity) {
     const int *idx_y = e.idx_y + (size_t)b * e.t_cap;
     // nearest target of a source: folded here from the one-pass kernel's per-chunk partials (nn_row_fold)
     const NnPart *rowpart = reinterpret_cast<const NnPart *>(e.nn_row) + (size_t)b * nn1_row_chunks(e.t_cap) * e.n_cap;
+    const bool rows_final = e.nn_mode == 1;          // latency shape: d2x / idx_x already hold the answer
     const bool use_cd = gm.S > 0 && e.w_cd != 0.f;
     const HeadCfg hcl = make_head_cfg(desc_at_level(e.desc, st.level));
     const bool use_reg = e.w_reg > 0.f && hcl.nonrig;
@@ -1369,7 +1478,7 @@ k_eng_loss(ndp_engine e, int parity) {
         if (use_cd) {
             float sx = 0.f;
             for (int i = t; i < gm.S; i += 256) {
-                const float v = nn_row_fold(rowpart, e.n_cap, gm.T, i).d2;
+                const float v = rows_final ? e.d2x[(size_t)b * e.n_cap + i] : nn_row_fold(rowpart, e.n_cap, gm.T, i).d2;
                 sx += (v >= e.trunc) ? 0.f : sqrtf(v);
             }
             sx = block_sum_256(sx, red);
@@ -1440,10 +1549,14 @@ k_eng_loss(ndp_engine e, int parity) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) g[a] = 2.0f * (w[a] - ldmk_t[3 * p + a]) * invK;
     } else if (p < n && use_cd) {
-        const NnPart nx = nn_row_fold(rowpart, e.n_cap, gm.T, i_self);
+        NnPart nx;
+        if (rows_final) { nx.d2 = e.d2x[(size_t)b * e.n_cap + i_self]; nx.idx = e.idx_x[(size_t)b * e.n_cap + i_self]; }
+        else {
+            nx = nn_row_fold(rowpart, e.n_cap, gm.T, i_self);
+            e.d2x[(size_t)b * e.n_cap + i_self] = nx.d2;             // kept for inspection; nothing on the path reads them
+            e.idx_x[(size_t)b * e.n_cap + i_self] = nx.idx;
+        }
         const float d2 = nx.d2;
-        e.d2x[(size_t)b * e.n_cap + i_self] = nx.d2;                 // kept for inspection; nothing on the path reads them
-        e.idx_x[(size_t)b * e.n_cap + i_self] = nx.idx;
         if (!(d2 >= e.trunc)) {
             const float *yy = tgt + 3 * nx.idx;
             const float inv = 1.0f / ((float)gm.S * sqrtf(d2));
@@ -2171,9 +2284,11 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     if (nn) if (int rc = set_smem((const void *)k_eng_nn, nn_lds)) return rc;
+    if (nn && e->nn_mode != 0 && e->nn_mode != 1) return fail(NDP_E_INVALID, "ndp_engine_run: nn_mode must be 0 (one pass) or 1 (latency shape)");
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
     const dim3 g_nn(nn1_row_chunks(e->t_cap), e->B);
+    const dim3 g_nn_lat(e->n_cap / 64 + e->t_cap / 64, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const dim3 g_loss((e->n_cap + 255) / 256 + 1, e->B);   // + 1: the loss / decision workgroup
     for (int k = 0; k < n_ticks; ++k) {
@@ -2182,7 +2297,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         int j = 0;
 #define NDP_EV() do { if (q) (void)hipEventRecord(q[j++], s); } while (0)
         NDP_EV(); hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
-        NDP_EV(); if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, nn_lds, s, *e, parity, stage_x);
+        NDP_EV();
+        if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);
+        else if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, nn_lds, s, *e, parity, stage_x);
         NDP_EV(); hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         NDP_EV(); hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV(); hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);

@@ -35,11 +35,12 @@ class OptConfig:
 
 
 class BatchedEngine:
-    def __init__(self, desc: LayerDesc, cfg: OptConfig, B: int, n_cap: int, t_cap: int, device, G=None):
+    def __init__(self, desc: LayerDesc, cfg: OptConfig, B: int, n_cap: int, t_cap: int, device, G=None, nn_mode=None):
         # desc.nonrigidity = True means "every level but the first carries the gate" (nets.py:26); P is then the
         # parameter count of a gated level and level 0 uses a prefix-compatible shorter layout.
         self.lib = N.lib()
         self.desc, self.cfg, self.B = desc, cfg, B
+        self.nn_mode = nn_mode                     # None: chosen from B (see _mk_struct); 0 one-pass, 1 latency shape
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise N.NdpError("BatchedEngine needs a GPU device; there is no CPU fallback")
@@ -92,6 +93,8 @@ class BatchedEngine:
         e.w_cd, e.trunc = c.w_cd, c.trunc
         e.w_reg = c.w_reg if self.desc.nonrigidity else 0.0
         e.adam_w1, e.adam_b2, e.adam_w2, e.adam_eps = 1 - 0.9, 0.999, 1 - 0.999, 1e-8
+        # few resident pairs: the one-pass kernel has only t_cap/256 workgroups per pair; the latency shape has (n_cap + t_cap)/64
+        e.nn_mode = int(self.nn_mode) if self.nn_mode is not None else (1 if self.B * (self.t_cap // 256 + 1) < 256 else 0)
         for name in ("geom", "state", "pts", "ldmk_t", "tgt", "params", "gpart", "adam_m", "adam_v", "act", "heads",
                      "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "dO", "nn_row"):
             setattr(e, name, getattr(self, name).data_ptr())

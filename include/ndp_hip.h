@@ -191,6 +191,8 @@ typedef struct ndp_engine {
     const float *adam_tab;           /* [iters+1][2]: {neg_step, bc2_sqrt} for t = 1..iters     */
     float *dO;                       /* [B][n_cap][16] mlp_scale * dL/d(head outputs), this tick */
     float *nn_row;                   /* one-pass 1-NN row partials, B x ndp_engine_nn_workspace() floats (NULL if w_cd == 0) */
+    int nn_mode, pad_i;              /* 0: one-pass kernel (throughput, many pairs resident); 1: latency shape -- two passes in
+                                        64-query workgroups, S/64 + T/64 of them per pair -- for a handful of resident pairs   */
 } ndp_engine;
 
 /* Floats PER PAIR of the row-partial buffer of the one-pass nearest-neighbour kernel ({d2, idx} per source and

@@ -15,7 +15,7 @@ import torch
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--steps", "1", "--warmup", "0", "--pairs-per-step", "48", "--slots", "24", "--engines", "1",
-         "--no-cpu-baseline", "--no-roofline"]
+         "--no-cpu-baseline", "--no-roofline", "--no-latency"]
 
 
 def _run(cmd, env=None, timeout=1500):

@@ -195,7 +195,7 @@ def test_landmark_and_adam_bit_exact(dev):
 
 
 # ----------------------------------------------------------------------------- batched engine
-def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3, seed=7, G=None, ratio=0.001):
+def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3, seed=7, G=None, ratio=0.001, nn_mode=None):
     from deformationpyramid_amd.engine import BatchedEngine, OptConfig
     kw = VARIANTS[tag]
     cfg = OptConfig(m=m, iters=iters, early_stop=early_stop, w_cd=w_cd, trunc=trunc, break_threshold_ratio=ratio)
@@ -205,7 +205,7 @@ def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3,
         pyr = seeded_pyramid(seed + b, m=m, **kw)
         d = pyr.descs[0]
         if eng is None:
-            eng = BatchedEngine(d, cfg, B, n_cap=K + S, t_cap=max(T, 1), device=dev, G=G)
+            eng = BatchedEngine(d, cfg, B, n_cap=K + S, t_cap=max(T, 1), device=dev, G=G, nn_mode=nn_mode)
         # slots of different sizes: slot b drops 7*b samples and 3*b targets
         Kb, Sb, Tb = K, max(S - 7 * b, 0), max(T - 3 * b, 0)
         src = cloud(Kb + Sb, 100 + b)
@@ -540,6 +540,31 @@ def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name):
         np.testing.assert_array_equal(d2y, r["d2y"])
         np.testing.assert_array_equal(ix, r["idx_x"])
         np.testing.assert_array_equal(iy, r["idx_y"])
+
+
+@pytest.mark.parametrize("nn_mode", [0, 1])
+def test_engine_matches_oracle_at_the_bench_geometry(dev, nn_mode):
+    """What bench.py times: S = T = 2000 samples, G = 4 workgroups per pair, 8 resident pairs of slightly different sizes,
+    3 iterations x 2 levels -- with the one-pass nearest-neighbour kernel (nn_mode 0, the throughput shape) and with the
+    latency shape (nn_mode 1): identical step counts, loss and warped samples within the per-step budget."""
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=2000, T=2000, m=2, iters=3, early_stop=False,
+                                          w_cd=1.0, trunc=1e9, B=8, G=4, nn_mode=nn_mode)
+    assert eng.G == 4 and eng.c_engine.nn_mode == nn_mode
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.level == 2 and st.total_steps == 6
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+        assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+
+
+def test_engine_nn_shapes_are_bit_identical(dev):
+    """The two nearest-neighbour shapes of the engine must produce the same bits (losses, parameters) tick for tick."""
+    runs = []
+    for mode in (0, 1):
+        eng, states, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=700, T=650, m=2, iters=4, early_stop=False, w_cd=1.0,
+                                           trunc=0.05, B=3, nn_mode=mode)
+        runs.append((eng.params.clone(), [s.loss for s in states], eng.d2y.clone(), eng.idx_y.clone()))
+    assert runs[0][1] == runs[1][1]
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
 
 
 def test_config3_stress_samples_8192(dev):
