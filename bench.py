@@ -36,7 +36,7 @@ from deformationpyramid_amd.config import load_config            # noqa: E402
 from deformationpyramid_amd.loss import compute_flow_metrics     # noqa: E402
 from deformationpyramid_amd.parallel import aggregate            # noqa: E402
 from deformationpyramid_amd.registration import Registration     # noqa: E402
-from deformationpyramid_amd.synthetic import synthetic_pair      # noqa: E402
+from deformationpyramid_amd.synthetic import surface_pair, synthetic_pair      # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md)
 FLOP_FWD_PT = 68608
@@ -310,6 +310,20 @@ def main():
             out["roofline"]["hbm_frac"] = out["roofline"]["hbm_tbps"] / 8.0
         out["kernels_ms_per_tick"] = prof
         out["tick"] = {"ms": tick_ms, "achieved_tflops": algorithmic_flops(S, T, P) * active / (tick_ms * 1e-3) / 1e12}
+    if rank == 0 and n_gpus == 1 and not args.no_roofline:
+        # accuracy on pairs NDP actually solves: 8 partial-overlap SURFACE pairs (tests/golden/F10b holds the reference's
+        # own rows: full-EPE 6.1, AccS 35.6 %, AccR 62.6 %; zero flow: EPE 13.4, AccS 0.3 %) -- not timed
+        sp = [surface_pair(p) for p in range(8)]
+        torch.manual_seed(0)
+        res = model.register_batch([(a.to(dev), b.to(dev)) for a, b, _, _ in sp], slots=8, engines=1)
+        acc = None
+        for (w, _), (a, _, fg, ov) in zip(res, sp):
+            mtr = compute_flow_metrics(w - a.to(dev), fg.to(dev), ov.to(dev))
+            v = np.array(list(mtr.values()), dtype=np.float64)
+            acc = v if acc is None else acc + v
+        out["accuracy_surface_pairs"] = dict({k: float(x / 8) for k, x in zip(mtr.keys(), acc)},
+                                             reference={"full-epe": 6.12, "full-AccS": 35.6, "full-AccR": 62.6},
+                                             zero_flow={"full-epe": 13.36, "full-AccS": 0.3})
     if rank == 0 and n_gpus == 1 and not args.no_latency:
         out["latency"] = latency_profile(cfg, pairs)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:

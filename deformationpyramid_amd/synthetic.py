@@ -28,6 +28,36 @@ def synthetic_pair(p, n_total=16384, partial=True):
     return src, tgt, flow_gt, overlap
 
 
+def surface_pair(p, n_total=16384, partial=True):
+    """Seeded pair of SURFACE samples (what 4DMatch scans are): a star-shaped bumpy closed surface, sampled twice (source /
+    target base: no exact correspondences), target deformed by phi(q) = q + 0.05 sin(2.5 q + a_p), rotated about z by
+    0.25 rad and translated; partial overlap keeps the target samples whose base point has x < 0.2.  NDP solves these
+    (the volume-filling cubes of synthetic_pair are not what it is built for)."""
+    g = torch.Generator().manual_seed(3000 + p)
+    d = torch.randn(n_total, 3, generator=g, dtype=torch.float32)
+    d = d / d.norm(dim=1, keepdim=True)
+    ph = torch.rand(4, generator=g, dtype=torch.float32) * 6.2831853
+    r = 0.35 * (1.0 + 0.18 * torch.sin(3.0 * d[:, 0] + ph[0]) * torch.sin(2.0 * d[:, 1] + ph[1])
+                + 0.10 * torch.cos(4.0 * d[:, 2] + ph[2]))
+    q = d * r[:, None]
+    src, tgt_base = q[0::2].contiguous(), q[1::2].contiguous()
+    c, s = float(math.cos(0.25)), float(math.sin(0.25))
+    Rz = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    t = torch.tensor([0.08, -0.03, 0.05], dtype=torch.float32)
+
+    def phi(x):
+        return x + 0.05 * torch.sin(2.5 * x + ph[3])
+
+    tgt = phi(tgt_base) @ Rz.T + t
+    flow_gt = phi(src) @ Rz.T + t - src
+    if partial:
+        tgt = tgt[tgt_base[:, 0] < 0.2].contiguous()
+        overlap = src[:, 0] < 0.2
+    else:
+        overlap = torch.ones(src.shape[0], dtype=torch.bool)
+    return src, tgt, flow_gt, overlap
+
+
 def synthetic_landmarks(p, src, flow_gt, k=500, noise=0.005):
     g = torch.Generator().manual_seed(5000 + p)
     idx = torch.randperm(src.shape[0], generator=g)[:k]

@@ -111,6 +111,36 @@ def synthetic_pair(p, n_total=16384, partial=True):
     return src, tgt, flow_gt, overlap
 
 
+def surface_pair(p, n_total=16384, partial=True):
+    """(mirrors deformationpyramid_amd.synthetic.surface_pair; kept separate on purpose)  Seeded pair of SURFACE samples (what 4DMatch scans are): a star-shaped bumpy closed surface, sampled twice (source /
+    target base: no exact correspondences), target deformed by phi(q) = q + 0.05 sin(2.5 q + a_p), rotated about z by
+    0.25 rad and translated; partial overlap keeps the target samples whose base point has x < 0.2.  NDP solves these
+    (the volume-filling cubes of synthetic_pair are not what it is built for)."""
+    g = torch.Generator().manual_seed(3000 + p)
+    d = torch.randn(n_total, 3, generator=g, dtype=torch.float32)
+    d = d / d.norm(dim=1, keepdim=True)
+    ph = torch.rand(4, generator=g, dtype=torch.float32) * 6.2831853
+    r = 0.35 * (1.0 + 0.18 * torch.sin(3.0 * d[:, 0] + ph[0]) * torch.sin(2.0 * d[:, 1] + ph[1])
+                + 0.10 * torch.cos(4.0 * d[:, 2] + ph[2]))
+    q = d * r[:, None]
+    src, tgt_base = q[0::2].contiguous(), q[1::2].contiguous()
+    c, s = float(np.cos(0.25)), float(np.sin(0.25))
+    Rz = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+    t = torch.tensor([0.08, -0.03, 0.05], dtype=torch.float32)
+
+    def phi(x):
+        return x + 0.05 * torch.sin(2.5 * x + ph[3])
+
+    tgt = phi(tgt_base) @ Rz.T + t
+    flow_gt = phi(src) @ Rz.T + t - src
+    if partial:
+        tgt = tgt[tgt_base[:, 0] < 0.2].contiguous()
+        overlap = src[:, 0] < 0.2
+    else:
+        overlap = torch.ones(src.shape[0], dtype=torch.bool)
+    return src, tgt, flow_gt, overlap
+
+
 def ndp_config(EasyDict, **over):
     cfg = dict(deformation_model="NDP", device=torch.device("cpu"), iters=500, lr=0.01,
                max_break_count=15, break_threshold_ratio=0.001, w_reg=0.0, samples=2000,
@@ -298,6 +328,143 @@ def F9_landmarks(nets, loss_mod, **_):
     save("F9_landmarks", **out)
 
 
+def F9c_mixed_landmark_chamfer(nets, loss_mod, **_):
+    """Mixed objective of registration.py:189-197: landmarks and samples warped together, loss = landmark MSE +
+    w_cd * truncated Chamfer.  Level 0, 8 forced iterations: loss trace, gradients of step 0, parameters after step 3."""
+    K, S, T, w_cd, trunc, seed, level = 120, 300, 280, 0.5, 0.012, 41, 0   # trunc in squared units: cuts about a third of the terms
+    torch.manual_seed(seed)
+    pyr = nets.Deformation_Pyramid(depth=3, width=128, device="cpu", k0=-8, m=9, rotation_format="axis_angle", motion="SE3")
+    layer = pyr.pyramid[level]
+    g = torch.Generator().manual_seed(seed + 1)
+    c, s = float(np.cos(0.2)), float(np.sin(0.2))
+    Rz = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    src_ldmk = torch.rand(K, 3, generator=g) - 0.5
+    tgt_ldmk = (src_ldmk + 0.04 * torch.sin(4.0 * src_ldmk)) @ Rz.T + torch.tensor([0.03, -0.02, 0.01])
+    s_sample = torch.rand(S, 3, generator=g) - 0.5
+    t_sample = ((torch.rand(T, 3, generator=g) - 0.5) + 0.04) @ Rz.T + torch.tensor([0.03, -0.02, 0.01])
+    rec = {"src_ldmk": src_ldmk.numpy(), "tgt_ldmk": tgt_ldmk.numpy(), "s_sample": s_sample.numpy(), "t_sample": t_sample.numpy(),
+           "seed": np.int64(seed), "w_cd": np.float32(w_cd), "trunc": np.float32(trunc),
+           "wsum": np.float64(sum(v.double().abs().sum().item() for v in layer.parameters()))}
+    pyr.gradient_setup(optimized_level=level)
+    opt = torch.optim.Adam(layer.parameters(), lr=0.01)
+    losses, l_ld, l_cd = [], [], []
+    for it in range(8):
+        src_pts = torch.cat([src_ldmk, s_sample])                                 # registration.py:190-197
+        warped_pts, _ = pyr.warp(src_pts, max_level=level, min_level=level)
+        warped_ldmk, s_warped = warped_pts[:K], warped_pts[K:]
+        loss_ldmk = torch.mean(torch.sum((warped_ldmk - tgt_ldmk) ** 2, dim=-1))
+        loss_cd = loss_mod.compute_truncated_chamfer_distance(s_warped[None], t_sample[None], trunc=trunc)
+        loss = loss_ldmk + w_cd * loss_cd
+        losses.append(loss.item()); l_ld.append(loss_ldmk.item()); l_cd.append(loss_cd.item())
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            rec["warp0"] = warped_pts.detach().numpy().copy()
+            for k, v in layer.named_parameters():
+                rec[f"grad0.{k}"] = v.grad.numpy().copy()
+        opt.step()
+        if it == 2:
+            for k, v in layer.named_parameters():
+                rec[f"step3.{k}"] = v.detach().numpy().copy()
+    w, _ = pyr.warp(torch.cat([src_ldmk, s_sample]), max_level=level, min_level=level)
+    rec["warp_final"] = w.detach().numpy()
+    rec["losses"] = np.array(losses, dtype=np.float64)
+    rec["losses_ldmk"] = np.array(l_ld, dtype=np.float64)
+    rec["losses_cd"] = np.array(l_cd, dtype=np.float64)
+    rec["n_truncated0"] = np.int64(-1)
+    save("F9c_mixed", **rec)
+
+
+def _read_ply_numbers(path):
+    """Vertices and (fan-triangulated) faces of an ASCII PLY -- this tool's own few lines, not the product's reader."""
+    with open(path) as f:
+        lines = f.read().split("\n")
+    nv = nf = 0
+    props, cur, body = [], None, 0
+    for i, ln in enumerate(lines):
+        tok = ln.split()
+        if tok[:1] == ["element"]:
+            cur = tok[1]
+            if cur == "vertex":
+                nv = int(tok[2])
+            if cur == "face":
+                nf = int(tok[2])
+        elif tok[:1] == ["property"] and cur == "vertex":
+            props.append(tok[-1])
+        elif tok[:1] == ["end_header"]:
+            body = i + 1
+            break
+    cols = [props.index(c) for c in "xyz"]
+    v = np.array([[float(x) for x in ln.split()] for ln in lines[body:body + nv]], dtype=np.float64)[:, cols].astype(np.float32)
+    faces = []
+    for ln in lines[body + nv:body + nv + nf]:
+        t = [int(x) for x in ln.split()]
+        for j in range(2, t[0]):
+            faces.append((t[1], t[j], t[j + 1]))
+    return v, np.array(faces, dtype=np.int64)
+
+
+def F13_shape_transfer(nets, loss_mod, **_):
+    """The inline loop of shape_transfer.py:116-157 (Sim3 / euler, samples = 6000, every sample used) on 6000 seeded vertices
+    of each demo mesh: first 10 iterations of level 0 (loss trace, gradient checksums of step 0, parameters after step 3),
+    then the inference warp of ALL 24 856 source vertices through the nine levels (:160-164).  Also the mesh numbers a PLY
+    reader must reproduce (counts, bounding box, total area) -- numbers only, the files stay in /root/reference."""
+    sv, sf = _read_ply_numbers(os.path.join(REF, "sim3_demo", "AlienSoldier.ply"))
+    tv, tf = _read_ply_numbers(os.path.join(REF, "sim3_demo", "Ortiz.ply"))
+    out = {}
+    for tag, v, f in (("src", sv, sf), ("tgt", tv, tf)):
+        a = v[f[:, 0]].astype(np.float64); b = v[f[:, 1]].astype(np.float64); c = v[f[:, 2]].astype(np.float64)
+        out[f"mesh.{tag}.counts"] = np.array([v.shape[0], f.shape[0]])
+        out[f"mesh.{tag}.bbox"] = np.stack([v.min(0), v.max(0)])
+        out[f"mesh.{tag}.area"] = np.float64(0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1).sum())
+        out[f"mesh.{tag}.vsum"] = v.astype(np.float64).sum(0)
+        out[f"mesh.{tag}.fsum"] = np.int64(f.sum())
+    rng = np.random.default_rng(13)
+    src_pcd = torch.from_numpy(sv[rng.choice(sv.shape[0], 6000, replace=False)])
+    tgt_pcd = torch.from_numpy(tv[rng.choice(tv.shape[0], 6000, replace=False)])
+    torch.manual_seed(0)
+    NDP = nets.Deformation_Pyramid(depth=3, width=128, device="cpu", k0=-8, m=9, nonrigidity_est=False,
+                                   rotation_format="euler", motion="Sim3")
+    src_mean = src_pcd.mean(dim=0, keepdims=True)
+    tgt_mean = tgt_pcd.mean(dim=0, keepdims=True)
+    s_sample, t_sample = src_pcd - src_mean, tgt_pcd - tgt_mean
+    out["s_sample"], out["t_sample"] = s_sample.numpy(), t_sample.numpy()
+    level = 0
+    NDP.gradient_setup(optimized_level=level)
+    layer = NDP.pyramid[level]
+    out["wsum"] = np.float64(sum(v.double().abs().sum().item() for v in layer.parameters()))
+    optimizer = torch.optim.Adam(layer.parameters(), lr=0.01)
+    losses = []
+    for it in range(10):
+        s_warped, _ = NDP.warp(s_sample, max_level=level, min_level=level)
+        loss = loss_mod.compute_truncated_chamfer_distance(s_warped[None], t_sample[None], trunc=1e+9)
+        losses.append(loss.item())
+        optimizer.zero_grad()
+        loss.backward()
+        if it == 0:
+            for k, v in layer.named_parameters():
+                gr = v.grad.numpy()
+                out[f"grad0.{k}"] = gr.copy() if gr.size <= 1024 else gr.reshape(-1)[::37].copy()
+                out[f"gsum0.{k}"] = np.float64(gr.astype(np.float64).sum())
+                out[f"gabs0.{k}"] = np.float64(np.abs(gr.astype(np.float64)).sum())
+        optimizer.step()
+        if it == 2:
+            for k, v in layer.named_parameters():
+                a = v.detach().numpy()
+                out[f"step3.{k}"] = a.copy() if a.size <= 1024 else a.reshape(-1)[::37].copy()
+        print(f"  iter {it}: loss {losses[-1]:.6f}", flush=True)
+    out["losses"] = np.array(losses, dtype=np.float64)
+    for k, v in layer.named_parameters():
+        out[f"final.{k}"] = v.detach().numpy().copy()              # the trained level 0, so that the warp below can be replayed
+    NDP.gradient_setup(optimized_level=-1)
+    mesh_vert = torch.from_numpy(sv) - src_mean
+    with torch.no_grad():
+        warped_vert, _ = NDP.warp(mesh_vert)
+    out["mesh_vert"] = mesh_vert.numpy()
+    out["warped_vert"] = warped_vert.numpy()
+    save("F13_shape_transfer", **out)
+
+
 def F11_nonrigidity(nets, loss_mod, reg_mod, EasyDict, **_):
     """w_reg > 0: the nonrigidity gate (nets.py:100-103,132-135) and the BCE regulariser (registration.py:216-220)."""
     out = {}
@@ -470,6 +637,31 @@ def F10_benchmark(reg_mod, loss_mod, EasyDict, bench_pairs=8, **_):
          iters=np.array(iters), seeds=np.arange(bench_pairs))
 
 
+def F10b_surface_benchmark(reg_mod, loss_mod, EasyDict, bench_pairs=8, **_):
+    """Reference metric rows on SURFACE pairs NDP actually solves (AccS far above the do-nothing answers, which are
+    recorded next to it): the accuracy bar of the GPU path."""
+    rows, iters, keys, zero_rows, cent_rows = [], [], None, [], []
+    for p in range(bench_pairs):
+        src, tgt, flow_gt, overlap = surface_pair(p)
+        cfg = ndp_config(EasyDict)
+        warped, trace = _register_traced(reg_mod, EasyDict, cfg, src, tgt, seed=p)
+        m = loss_mod.compute_flow_metrics(warped - src, flow_gt, overlap)
+        keys = list(m.keys())
+        rows.append(list(m.values()))
+        zero_rows.append(list(loss_mod.compute_flow_metrics(torch.zeros_like(src), flow_gt, overlap).values()))
+        cent = (tgt.mean(0) - src.mean(0))[None].expand_as(src)
+        cent_rows.append(list(loss_mod.compute_flow_metrics(cent, flow_gt, overlap).values()))
+        iters.append([len(t) for t in trace])
+        print(f"pair {p}: iters {sum(iters[-1])}  full-epe {m['full-epe']:.3f} AccS {m['full-AccS']:.2f} AccR {m['full-AccR']:.2f}"
+              f"   zero-flow epe {zero_rows[-1][0]:.3f}  centroid epe {cent_rows[-1][0]:.3f}", flush=True)
+    first = surface_pair(0)
+    save("F10b_surface_benchmark", keys=np.array(keys), rows=np.array(rows, dtype=np.float64), iters=np.array(iters),
+         seeds=np.arange(bench_pairs), zero_flow_rows=np.array(zero_rows, dtype=np.float64),
+         centroid_rows=np.array(cent_rows, dtype=np.float64),
+         gen_src_head=first[0][:16].numpy(), gen_tgt_head=first[1][:16].numpy(), gen_flow_head=first[2][:16].numpy(),
+         gen_counts=np.array([first[0].shape[0], first[1].shape[0], int(first[3].sum())]))
+
+
 def F12_nsfp(nets, loss_mod, reg_mod, EasyDict, **_):
     """NSFP baseline: Neural_Prior init / forward / parameter gradients through the Chamfer loss,
     and optimize_neural_SFlow end to end with every evaluated loss recorded."""
@@ -549,7 +741,9 @@ def main():
     todo = {
         "F1": F1_init, "F2": F2_layer_forward, "F3": F3_chamfer, "F4": F4_F5_iteration,
         "F7": F7_end_to_end, "F8": F8_metrics, "F9": F9_landmarks, "F9b": F9b_lndp_end_to_end,
-        "F10": F10_benchmark, "F11": F11_nonrigidity, "F12": F12_nsfp,
+        "F9c": F9c_mixed_landmark_chamfer,
+        "F10": F10_benchmark, "F10b": F10b_surface_benchmark, "F11": F11_nonrigidity, "F12": F12_nsfp,
+        "F13": F13_shape_transfer,
     }
     only = [s for s in args.only.split(",") if s]
     for k, fn in todo.items():

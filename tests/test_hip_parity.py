@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._helpers import VARIANTS, seeded_pyramid, scale_heads, rel_err
+from tests._helpers import VARIANTS, seeded_pyramid, scale_heads, rel_err, flat_from_named
 
 pytestmark = pytest.mark.gpu
 K0 = -8
@@ -259,6 +259,56 @@ def test_engine_landmark_only_and_mixed(dev):
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
         assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+
+
+def test_F9c_engine_mixed_objective_against_the_reference(dev, golden):
+    """The mixed landmark + truncated-Chamfer objective (registration.py:189-197) through the HIP engine, against the
+    trace captured from the reference: loss of evaluations 1..8 and the parameters after three Adam steps."""
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    g = golden("F9c_mixed")
+    K, S, T = g["src_ldmk"].shape[0], g["s_sample"].shape[0], g["t_sample"].shape[0]
+    pts = torch.from_numpy(np.concatenate([g["src_ldmk"], g["s_sample"]]))
+    ref = g["losses"]
+    pyr = seeded_pyramid(int(g["seed"]), **VARIANTS["se3aa"])
+    d = pyr.descs[0]
+    for n_eval in (1, 4, 8):
+        cfg = OptConfig(m=1, iters=n_eval, early_stop=False, w_cd=float(g["w_cd"]), trunc=float(g["trunc"]))
+        eng = BatchedEngine(d, cfg, 1, n_cap=K + S, t_cap=T, device=dev)
+        eng.load(0, pts, K, S, torch.from_numpy(g["tgt_ldmk"]), torch.from_numpy(g["t_sample"]), pyr.store[:1])
+        st = eng.run_until_done(chunk=n_eval)[0]
+        assert st.total_evals == n_eval
+        assert abs(st.loss - ref[n_eval - 1]) < (2e-6 if n_eval == 1 else 1e-3) * ref[n_eval - 1], (n_eval, st.loss, ref[n_eval - 1])
+    cfg = OptConfig(m=1, iters=3, early_stop=False, w_cd=float(g["w_cd"]), trunc=float(g["trunc"]))
+    eng = BatchedEngine(d, cfg, 1, n_cap=K + S, t_cap=T, device=dev)
+    eng.load(0, pts, K, S, torch.from_numpy(g["tgt_ldmk"]), torch.from_numpy(g["t_sample"]), pyr.store[:1])
+    eng.run_until_done(chunk=3)
+    got = eng.params[0, 0, :d.param_count].cpu().numpy()
+    for name, off, shape in d.named_slices():
+        ref3, r0 = g[f"step3.{name}"], g[f"grad0.{name}"]
+        mask = np.abs(r0) > 1e-3 * np.abs(r0).max()
+        assert np.abs(got[off:off + ref3.size].reshape(ref3.shape) - ref3)[mask].max() < 2e-4, name
+
+
+def test_F13_shape_transfer_on_the_engine_against_the_reference(dev, golden):
+    """BASELINE config 4 against reference data: Sim3 / euler, 6000 + 6000 seeded mesh vertices, ten iterations of level 0
+    (loss of evaluations 1 and 10), then all 24 856 source vertices through the nine levels (1e-4 on coordinates)."""
+    from deformationpyramid_amd import ops
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    g = golden("F13_shape_transfer")
+    pyr = seeded_pyramid(0, **VARIANTS["sim3eu"])
+    d = pyr.descs[0]
+    S, T = g["s_sample"].shape[0], g["t_sample"].shape[0]
+    ref = g["losses"]
+    for n_eval in (1, 10):
+        eng = BatchedEngine(d, OptConfig(m=1, iters=n_eval, early_stop=False), 1, n_cap=S, t_cap=T, device=dev)
+        eng.load(0, torch.from_numpy(g["s_sample"]), 0, S, None, torch.from_numpy(g["t_sample"]), pyr.store[:1])
+        st = eng.run_until_done(chunk=n_eval)[0]
+        assert abs(st.loss - ref[n_eval - 1]) < (2e-6 if n_eval == 1 else 2e-3) * ref[n_eval - 1], (n_eval, st.loss, ref[n_eval - 1])
+    store = pyr.store.clone()
+    named = {name: g[f"final.{name}"] for name, _, _ in d.named_slices()}
+    store[0, :d.param_count] = torch.from_numpy(flat_from_named(d, named))
+    got = ops.pyramid_fwd(d, 9, K0, store.to(dev).contiguous(), torch.from_numpy(np.ascontiguousarray(g["mesh_vert"])).to(dev)).cpu().numpy()
+    assert got.shape == (24856, 3) and np.abs(got - g["warped_vert"]).max() < 1e-4
 
 
 def test_engine_is_deterministic_and_G_independent_in_loss(dev):

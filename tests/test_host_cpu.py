@@ -134,6 +134,21 @@ def test_synthetic_pair_matches_the_golden_generator(golden):
     assert 0 < overlap.sum() < overlap.numel()
 
 
+def test_surface_pair_matches_the_golden_generator(golden):
+    """The product's surface-pair generator and the one the F10b fixture was captured with are the same function."""
+    from deformationpyramid_amd.synthetic import surface_pair
+    g = golden("F10b_surface_benchmark")
+    src, tgt, flow_gt, overlap = surface_pair(0)
+    np.testing.assert_array_equal(src[:16].numpy(), g["gen_src_head"])
+    np.testing.assert_array_equal(tgt[:16].numpy(), g["gen_tgt_head"])
+    np.testing.assert_array_equal(flow_gt[:16].numpy(), g["gen_flow_head"])
+    assert [src.shape[0], tgt.shape[0], int(overlap.sum())] == list(g["gen_counts"])
+    # the fixture is only worth something if the reference solves the problem: far better than doing nothing
+    k = list(g["keys"])
+    assert g["rows"][:, k.index("full-epe")].mean() < 0.6 * g["zero_flow_rows"][:, k.index("full-epe")].mean()
+    assert g["rows"][:, k.index("full-AccS")].mean() > 25.0 > g["centroid_rows"][:, k.index("full-AccS")].mean()
+
+
 def test_chamfer_argument_validation():
     from deformationpyramid_amd.loss import compute_truncated_chamfer_distance as cd
     with pytest.raises(ValueError):

@@ -4,6 +4,8 @@ vectors captured FROM THE REFERENCE (tests/golden/make_golden.py, run in the bui
 These are `not gpu` tests.  Tolerances are float32 round-off class: the reference's sgemm and
 the oracle's fmaf chains sum in different orders.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -184,6 +186,101 @@ def test_F9_landmark_iterations(golden):
         r0 = g[f"ldmk.L0.grad0.{name}"]
         got = rec["grad0"][off:off + r0.size].reshape(r0.shape)
         assert rel_err(got, r0) < 1e-4, name
+
+
+def test_F9c_mixed_landmark_plus_truncated_chamfer(golden):
+    """registration.py:189-197 (landmarks and samples warped together, landmark MSE + w_cd * truncated Chamfer) as the
+    reference computes it: loss trace of 8 forced iterations, gradients of step 0, parameters after step 3."""
+    g = golden("F9c_mixed")
+    K, w_cd, trunc = g["src_ldmk"].shape[0], float(g["w_cd"]), float(g["trunc"])
+    pyr = seeded_pyramid(int(g["seed"]), **VARIANTS["se3aa"])
+    assert abs(wsum(pyr, 0) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    d = pyr.descs[0]
+    cd = cdesc(d)
+    p0 = pyr.store[0, :d.param_count].numpy().copy()
+    pts = np.concatenate([g["src_ldmk"], g["s_sample"]])
+    # one step by hand: the two gradient parts combine as the reference's autograd does
+    w = O.level_fwd(cd, p0, 0, K0, pts)
+    np.testing.assert_allclose(w, g["warp0"], rtol=0, atol=1e-6)
+    L_l, g_l = O.landmark(w[:K], g["tgt_ldmk"])
+    r = O.chamfer(w[K:], g["t_sample"], trunc=trunc)
+    assert 0 < (r["d2x"] >= trunc).sum() < r["d2x"].size           # the truncation really cuts some terms, not all
+    assert abs(float(L_l) - g["losses_ldmk"][0]) < 2e-6 * g["losses_ldmk"][0]
+    assert abs(float(r["loss"]) - g["losses_cd"][0]) < 2e-6 * g["losses_cd"][0]
+    grads = O.level_bwd(cd, p0, 0, K0, pts, np.concatenate([g_l, w_cd * r["gx"]]))
+    for name, off, shape in d.named_slices():
+        ref = g[f"grad0.{name}"]
+        assert rel_err(grads[off:off + ref.size].reshape(ref.shape), ref) < 1e-4, name
+    # the whole loop through the oracle's optimiser (what the engine tests compare against)
+    out = O.optimize([cd], p0, pts, K, pts.shape[0] - K, g["tgt_ldmk"], g["t_sample"], k0=K0, iters=8, w_cd=w_cd,
+                     trunc=trunc, early_stop=False, nthreads=4)
+    ref = g["losses"]
+    assert abs(out["loss_trace"][0] - ref[0]) < 2e-6 * ref[0]
+    assert np.abs(out["loss_trace"] - ref).max() < 1e-3 * ref.max()
+    out3 = O.optimize([cd], p0, pts, K, pts.shape[0] - K, g["tgt_ldmk"], g["t_sample"], k0=K0, iters=3, w_cd=w_cd,
+                      trunc=trunc, early_stop=False, nthreads=4)
+    for name, off, shape in d.named_slices():
+        ref3, r0 = g[f"step3.{name}"], g[f"grad0.{name}"]
+        mask = np.abs(r0) > 1e-3 * np.abs(r0).max()
+        got3 = out3["params_all"][off:off + ref3.size].reshape(ref3.shape)
+        assert np.abs(got3 - ref3)[mask].max() < 2e-4, name
+
+
+def _f13_setup(g):
+    pyr = seeded_pyramid(0, **VARIANTS["sim3eu"])
+    assert abs(wsum(pyr, 0) - float(g["wsum"])) < 1e-6 * float(g["wsum"])
+    return pyr, pyr.descs[0]
+
+
+def test_F13_shape_transfer_loop_and_vertex_warp(golden):
+    """shape_transfer.py:116-166 on 6000 seeded vertices of each demo mesh (Sim3 / euler): the oracle follows the
+    reference's first ten iterations of level 0 and reproduces the 24 856-vertex inference warp."""
+    g = golden("F13_shape_transfer")
+    pyr, d = _f13_setup(g)
+    cd = cdesc(d)
+    p0 = pyr.store[0, :d.param_count].numpy().copy()
+    S = g["s_sample"].shape[0]
+    out = O.optimize([cd], p0, g["s_sample"], 0, S, None, g["t_sample"], k0=K0, iters=10, early_stop=False, nthreads=8)
+    ref = g["losses"]
+    assert abs(out["loss_trace"][0] - ref[0]) < 2e-6 * ref[0]
+    assert np.abs(out["loss_trace"] - ref).max() < 2e-3 * ref.max()
+    # gradients of step 0 (checksums + strided slices of the big matrices)
+    w = O.level_fwd(cd, p0, 0, K0, g["s_sample"], nthreads=8)
+    r = O.chamfer(w, g["t_sample"], nthreads=8)
+    grads = O.level_bwd(cd, p0, 0, K0, g["s_sample"], r["gx"], nthreads=8)
+    for name, off, shape in d.named_slices():
+        n = int(np.prod(shape))
+        got = grads[off:off + n]
+        assert abs(got.astype(np.float64).sum() - float(g[f"gsum0.{name}"])) < 2e-4 * float(g[f"gabs0.{name}"]) + 1e-9, name
+        refv = g[f"grad0.{name}"].reshape(-1)
+        gotv = got if n <= 1024 else got[::37]
+        assert rel_err(gotv, refv) < 2e-4, name
+    # inference warp of all source vertices with the reference's trained level 0 and the untouched levels 1..8
+    params_all = np.concatenate([pyr.store[i, :d.param_count].numpy() for i in range(9)])
+    named = {name: g[f"final.{name}"] for name, _, _ in d.named_slices()}
+    params_all[:d.param_count] = flat_from_named(d, named)
+    got = O.pyramid_fwd([cd] * 9, K0, params_all, g["mesh_vert"], nthreads=8)
+    assert got.shape == (24856, 3)
+    assert np.abs(got - g["warped_vert"]).max() < 1e-5
+
+
+def test_ply_reader_reproduces_the_demo_mesh_numbers(golden):
+    """meshio.read_ply_ascii against numbers captured from sim3_demo/*.ply (counts, bounding box, total area, checksums).
+    The meshes live in /root/reference and never travel: the check runs where they exist."""
+    from deformationpyramid_amd.meshio import read_ply_ascii
+    g = golden("F13_shape_transfer")
+    root = "/root/reference/sim3_demo"
+    if not os.path.isdir(root):
+        pytest.skip("demo meshes are only present in the build container")
+    for tag, name in (("src", "AlienSoldier.ply"), ("tgt", "Ortiz.ply")):
+        v, f = read_ply_ascii(os.path.join(root, name))
+        assert [v.shape[0], f.shape[0]] == list(g[f"mesh.{tag}.counts"])
+        np.testing.assert_array_equal(np.stack([v.min(0), v.max(0)]), g[f"mesh.{tag}.bbox"])
+        a, b, c = (v[f[:, k]].astype(np.float64) for k in range(3))
+        area = 0.5 * np.linalg.norm(np.cross(b - a, c - a), axis=1).sum()
+        assert abs(area - float(g[f"mesh.{tag}.area"])) < 1e-9 * area
+        np.testing.assert_allclose(v.astype(np.float64).sum(0), g[f"mesh.{tag}.vsum"], rtol=1e-12)
+        assert int(f.sum()) == int(g[f"mesh.{tag}.fsum"])
 
 
 # ------------------------------------------------------------------- F6/F7: early stop + end to end

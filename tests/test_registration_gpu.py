@@ -104,6 +104,39 @@ def test_register_batch_reproduces_reference_benchmark_metrics(cfg, golden):
     assert abs(np.mean(iters) - g["iters"].sum(1).mean()) < 0.25 * g["iters"].sum(1).mean()
 
 
+def test_register_reproduces_reference_metrics_on_surface_pairs(cfg, golden):
+    """F10b: 8 seeded pairs of partial-overlap SURFACE samples on which the reference reaches full-EPE 5-6 (zero flow:
+    10-13) and AccS ~40 %.  The 8-pair means of the GPU path must sit within 10 % of the reference's, and the do-nothing
+    answers (zero flow, centroid shift) must FAIL the same assert -- the bar discriminates."""
+    from deformationpyramid_amd.loss import compute_flow_metrics
+    from deformationpyramid_amd.registration import Registration
+    from deformationpyramid_amd.synthetic import surface_pair
+    g = golden("F10b_surface_benchmark")
+    keys = list(g["keys"])
+    ref = g["rows"]
+    pairs, gts = [], []
+    for p in g["seeds"]:
+        src, tgt, flow_gt, overlap = surface_pair(int(p))
+        pairs.append((src, tgt))
+        gts.append((flow_gt, overlap))
+    rows = []
+    model = Registration(cfg)
+    for p, (src, tgt) in zip(g["seeds"], pairs):
+        torch.manual_seed(int(p))                              # the fixture seeds per pair
+        model.load_pcds(src.numpy(), tgt.numpy())
+        warped, cnt, _ = model.register()
+        m = compute_flow_metrics(warped.cpu() - src, *gts[len(rows)])
+        rows.append([m[k] for k in keys])
+    rows = np.array(rows)
+
+    def within(candidate):
+        return all(abs(candidate[:, keys.index(k)].mean() - ref[:, keys.index(k)].mean()) < 0.10 * ref[:, keys.index(k)].mean()
+                   for k in ("full-epe", "full-AccS", "full-AccR", "vis-epe", "vis-AccS"))
+
+    assert within(rows), {k: (rows[:, keys.index(k)].mean(), ref[:, keys.index(k)].mean()) for k in ("full-epe", "full-AccS", "full-AccR", "vis-epe", "vis-AccS")}
+    assert not within(g["zero_flow_rows"]) and not within(g["centroid_rows"])
+
+
 def test_register_batch_equals_sequential_register(cfg):
     """Same seed, same pairs: the batched path consumes the CPU RNG in the same order as sequential
     register() calls and lands on the same answer up to trajectory noise; with prefetch on or off the
