@@ -36,7 +36,8 @@ from deformationpyramid_amd.config import load_config            # noqa: E402
 from deformationpyramid_amd.loss import compute_flow_metrics     # noqa: E402
 from deformationpyramid_amd.parallel import aggregate            # noqa: E402
 from deformationpyramid_amd.registration import Registration     # noqa: E402
-from deformationpyramid_amd.synthetic import surface_pair, synthetic_pair      # noqa: E402
+from deformationpyramid_amd.config import Config                 # noqa: E402
+from deformationpyramid_amd.synthetic import surface_pair, synthetic_landmarks, synthetic_pair      # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md)
 FLOP_FWD_PT = 68608
@@ -52,7 +53,7 @@ def algorithmic_flops(S, T, P):
 def kernel_profile(model, pairs, slots, n_ticks=24):
     """Per-kernel average launch durations (HIP events on the launch stream) over ticks in which
     every slot is active at level 0.  Returns dict kernel -> ms per launch, plus the engine."""
-    preps = [model._prepare(s, t, None) for s, t in pairs[:slots]]
+    preps = [model._prepare(it[0], it[1], it[2] if len(it) > 2 else None) for it in pairs[:slots]]
     eng = model._engine(len(preps), preps[0])
     for b, p in enumerate(preps):
         eng.load_jobs([p.load_job(b)])
@@ -68,11 +69,11 @@ def pmc_traffic(kernel, pairs):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled
     per the gfx950 correction, WRITE_SIZE as is; collected by tools/pmc_traffic.sh at 128 pairs per launch and
     scaled linearly to this launch's pair count).  None when no such profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
     try:
-        rec = json.load(open(path))[kernel]
+        path = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_hbm_traffic_pmc.json"))[-1]   # newest round
+        rec = json.load(open(os.path.join(ROOT, "profiles", path)))[kernel]
         return rec["hbm_bytes_per_launch"] * pairs / rec["pairs_per_launch"]
-    except (OSError, KeyError, ValueError):
+    except (OSError, KeyError, ValueError, IndexError):
         return None
 
 
@@ -107,43 +108,89 @@ def latency_profile(cfg, pairs, repeats=5):
             "tick_ms": sum(ms) / n_ticks}
 
 
-def cpu_baseline(cfg, src, tgt):
-    """The oracle (oracle/ndp_oracle.c, a parity-pinned C port of the reference path) timed on this
-    box's host cores on ONE full pair with the bench's settings."""
+def _cpu_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False) or logical
+    except Exception:
+        physical = logical
+    return model, physical, logical
+
+
+def cpu_baseline(cfg, pairs):
+    """The reference's per-pair path on this box's host cores, two ways, both parity-pinned test infrastructure:
+      port-c     oracle/ndp_oracle.c -- the bit-faithful scalar C restatement, OpenMP over the points;
+      port-torch oracle/ndp_torch_ref.py -- the same loop on plain torch-CPU ops (BLAS-backed linear layers, autograd,
+                 torch.optim.Adam): what the reference's own CPU path amounts to.
+    Fixed policy (no calibration): threads = min(physical cores, 32) -- OpenMP over 2000 points and 128-wide GEMMs stop
+    scaling there -- the process restricted to that many cores, 1 warm-up pair, then 3 pairs (the bench's pairs 1..3,
+    NDP.yaml unchanged, full register() work incl. the 8192-pt final warp); value = pairs / total seconds of the faster
+    port, spread = (max - min) / median of its per-pair times."""
     from oracle import ndp_oracle as O
+    from oracle import ndp_torch_ref as T
     from deformationpyramid_amd.nets import Deformation_Pyramid
-    cores = os.cpu_count() or 1
-    torch.manual_seed(0)
-    pyr = Deformation_Pyramid(depth=cfg.depth, width=cfg.width, device="cpu", k0=cfg.k0, m=cfg.m,
-                              rotation_format=cfg.rotation_format, motion=cfg.motion_type)
-    d = pyr.descs[0]
-    cd = O.make_desc(d.width, d.n_hidden, d.motion, d.rotfmt, d.nonrigidity, d.mlp_scale)
-    src = src.cpu() - src.cpu().mean(0, keepdim=True)
-    tgt = tgt.cpu() - tgt.cpu().mean(0, keepdim=True)
-    s = src[torch.randperm(src.shape[0])[: cfg.samples]].numpy()
-    t = tgt[torch.randperm(tgt.shape[0])[: cfg.samples]].numpy()
-    pa = np.concatenate([pyr.store[i, :d.param_count].numpy() for i in range(cfg.m)])
+    model_name, physical, logical = _cpu_info()
+    threads = max(1, min(physical, 32))
+    aff = None
+    try:
+        aff = os.sched_getaffinity(0)
+        os.sched_setaffinity(0, set(sorted(aff)[:threads]))
+    except (AttributeError, OSError):
+        aff = None
+    old_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
     O.lib()
-    # OpenMP over 2000 points stops scaling long before 256 threads: calibrate on 3 iterations
-    best, used = None, 1
-    for nt in [c for c in (4, 8, 16, 32, 64, 128) if c <= cores] or [1]:
-        t0 = time.time()
-        O.optimize([cd], pa[:d.param_count], s, 0, s.shape[0], None, t, k0=cfg.k0, iters=3, early_stop=False, nthreads=nt)
-        dt = time.time() - t0
-        if best is None or dt < best:
-            best, used = dt, nt
-    cores = used
-    t0 = time.time()
-    r = O.optimize([cd] * cfg.m, pa, s, 0, s.shape[0], None, t, k0=cfg.k0, iters=cfg.iters,
-                   max_break_count=cfg.max_break_count, ratio=cfg.break_threshold_ratio, lr=cfg.lr,
-                   nthreads=cores)
-    descs = [cd] * cfg.m
-    O.pyramid_fwd(descs, cfg.k0, r["params_all"], src.numpy(), nthreads=cores)
-    dt = time.time() - t0
-    return {"value": 1.0 / dt, "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"1 full 8192-pt pair, NDP.yaml, {int(r['steps'])} Adam iterations, {dt:.2f} s "
-                      f"({1e3 * dt / max(int(r['steps']), 1):.1f} ms/iter), OpenMP over points",
-            "ms_per_iter": 1e3 * dt / max(int(r["steps"]), 1)}
+    runs = {"port-c": [], "port-torch": []}
+    iters = {"port-c": [], "port-torch": []}
+    try:
+        for k, (src, tgt) in enumerate(pairs[:4]):
+            torch.manual_seed(k)
+            pyr = Deformation_Pyramid(depth=cfg.depth, width=cfg.width, device="cpu", k0=cfg.k0, m=cfg.m,
+                                      rotation_format=cfg.rotation_format, motion=cfg.motion_type)
+            d = pyr.descs[0]
+            cd = O.make_desc(d.width, d.n_hidden, d.motion, d.rotfmt, d.nonrigidity, d.mlp_scale)
+            src_c = src.cpu() - src.cpu().mean(0, keepdim=True)
+            tgt_c = tgt.cpu() - tgt.cpu().mean(0, keepdim=True)
+            s = src_c[torch.randperm(src_c.shape[0])[: cfg.samples]].contiguous()
+            t = tgt_c[torch.randperm(tgt_c.shape[0])[: cfg.samples]].contiguous()
+            pa = np.concatenate([pyr.store[i, :d.param_count].numpy() for i in range(cfg.m)])
+            t0 = time.perf_counter()
+            r = O.optimize([cd] * cfg.m, pa, s.numpy(), 0, s.shape[0], None, t.numpy(), k0=cfg.k0, iters=cfg.iters,
+                           max_break_count=cfg.max_break_count, ratio=cfg.break_threshold_ratio, lr=cfg.lr, nthreads=threads)
+            O.pyramid_fwd([cd] * cfg.m, cfg.k0, r["params_all"], src_c.numpy(), nthreads=threads)
+            dt_c = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            levels, _, _, steps = T.optimize(pyr.store[:, :d.param_count], s, t, m=cfg.m, k0=cfg.k0, iters=cfg.iters, lr=cfg.lr,
+                                             max_break_count=cfg.max_break_count, ratio=cfg.break_threshold_ratio)
+            T.pyramid_forward(levels, src_c, cfg.k0)
+            dt_t = time.perf_counter() - t0
+            if k:                                          # pair 0 is the warm-up
+                runs["port-c"].append(dt_c); iters["port-c"].append(int(r["steps"]))
+                runs["port-torch"].append(dt_t); iters["port-torch"].append(int(steps))
+    finally:
+        torch.set_num_threads(old_threads)
+        if aff is not None:
+            os.sched_setaffinity(0, aff)
+    rep = {}
+    for kind, ts in runs.items():
+        med = sorted(ts)[len(ts) // 2]
+        rep[kind] = {"pairs_per_s": len(ts) / sum(ts), "s_per_pair": [round(x, 3) for x in ts],
+                     "ms_per_iter": 1e3 * sum(ts) / max(sum(iters[kind]), 1), "adam_iters": iters[kind],
+                     "spread": (max(ts) - min(ts)) / med}
+    best = max(rep, key=lambda k: rep[k]["pairs_per_s"])
+    return {"value": rep[best]["pairs_per_s"], "unit": "pairs/s", "cores": threads, "kind": best,
+            "sample": f"1 warm-up + {len(runs[best])} full 8192-pt pairs, NDP.yaml unchanged, register() work incl. the final warp; "
+                      f"{threads} threads on {threads} of {physical} physical cores ({logical} logical), {model_name}",
+            "ms_per_iter": rep[best]["ms_per_iter"], "cpu_model": model_name, "physical_cores": physical, "ports": rep}
 
 
 def self_launch(n):
@@ -171,6 +218,9 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 32 x slots)")
     ap.add_argument("--chunk", type=int, default=4, help="ticks between host polls")
     ap.add_argument("--engines", type=int, default=3, help="independent engines (HIP streams) per GPU, `slots` pairs each")
+    ap.add_argument("--config", default="A", choices=list("ABCDE"),
+                    help="SURVEY 8(d) workload: A NDP.yaml faithful (the headline line); B fixed work (= --fixed-work); C samples = 8192; "
+                         "D Sim3/euler, 6000 samples of 24 856-pt clouds (shape transfer); E LNDP.yaml, 500 landmarks, m = 10")
     ap.add_argument("--fixed-work", action="store_true",
                     help="SURVEY 8(d) config B: early stop off, 50 iterations x 9 levels = 450 Adam steps per pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -211,14 +261,40 @@ def main():
 
     cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=local_rank)
     if args.fixed_work:
-        cfg.iters, cfg.max_break_count = 50, 10 ** 9
+        args.config = "B"
     B = args.slots
-    NP = args.pairs_per_step or 32 * B
+    workload = ("synthetic 8192-pt pair, NDP.yaml (SE3/axis-angle, m=9, samples=2000, iters<=500, early stop on), "
+                "full register(): init + level/Adam loop + 8192-pt final warp")
+    make_pair = lambda i: synthetic_pair(i)
+    if args.config == "B":
+        cfg.iters, cfg.max_break_count = 50, 10 ** 9
+        workload = ("synthetic 8192-pt pair, NDP.yaml with iters=50 and the early stop off (fixed work: 450 Adam iterations per "
+                    "pair), full register(): init + level/Adam loop + 8192-pt final warp")
+    elif args.config == "C":
+        cfg.samples = 8192
+        B = min(B, 32)
+        workload = ("synthetic 8192-pt pair, NDP.yaml with samples=8192 (every point a Chamfer sample: S=8192, T~6144), "
+                    "full register()")
+    elif args.config == "D":
+        cfg = Config(cfg, motion_type="Sim3", rotation_format="euler", samples=6000)
+        B = min(B, 32)
+        make_pair = lambda i: surface_pair(i, n_total=2 * 24856, partial=False)
+        workload = ("shape-transfer shape: Sim3/euler, 6000 Chamfer samples of 24 856-pt surface clouds (the vertex count of "
+                    "sim3_demo/AlienSoldier.ply), m=9, early stop on, full register() incl. the 24 856-pt final warp")
+    elif args.config == "E":
+        cfg = load_config(os.path.join(ROOT, "config", "LNDP.yaml"), device=local_rank)
+        workload = ("LNDP.yaml (supervised path): 500 synthetic landmark correspondences per 8192-pt pair (noise 0.005), m=10, "
+                    "w_cd=0: landmark MSE only, full register() incl. the 8192-pt final warp")
+    NP = args.pairs_per_step or (32 * B if args.config in "ABE" else 8 * B)
     # inputs resident in HBM before the timed region
     pairs, gts = [], []
     for i in range(NP):
-        src, tgt, flow_gt, overlap = synthetic_pair(rank * NP + i)
-        pairs.append((src.to(dev), tgt.to(dev)))
+        src, tgt, flow_gt, overlap = make_pair(rank * NP + i)
+        if args.config == "E":
+            ls, lt = synthetic_landmarks(rank * NP + i, src, flow_gt, k=500)
+            pairs.append((src.to(dev), tgt.to(dev), (ls.to(dev), lt.to(dev))))
+        else:
+            pairs.append((src.to(dev), tgt.to(dev)))
         gts.append((flow_gt, overlap))
     model = Registration(cfg)
     torch.manual_seed(rank)
@@ -248,8 +324,8 @@ def main():
     # accuracy of the last step's pairs (not timed)
     keys = None
     msum = None
-    for (warped, _), (src, _), (flow_gt, overlap) in zip(last, pairs, gts):
-        mtr = compute_flow_metrics(warped - src, flow_gt.to(dev), overlap.to(dev))
+    for (warped, _), item, (flow_gt, overlap) in zip(last, pairs, gts):
+        mtr = compute_flow_metrics(warped - item[0], flow_gt.to(dev), overlap.to(dev))
         keys = list(mtr.keys())
         v = np.array([mtr[k] for k in keys], dtype=np.float64)
         msum = v if msum is None else msum + v
@@ -274,11 +350,7 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "config": {"workload": ("synthetic 8192-pt pair, NDP.yaml with iters=50 and the early stop off (fixed work: 450 Adam "
-                                "iterations per pair), full register(): init + level/Adam loop + 8192-pt final warp"
-                                if args.fixed_work else
-                                "synthetic 8192-pt pair, NDP.yaml (SE3/axis-angle, m=9, samples=2000, iters<=500, "
-                                "early stop on), full register(): init + level/Adam loop + 8192-pt final warp"),
+        "config": {"workload": workload, "survey_8d_config": args.config,
                    "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B * args.engines, "engines_per_gpu": args.engines, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective",
                    "backend": ("none" if not use_dist else ("rccl" if backend == "nccl" else backend)),
                    "seeds": "rank r registers synthetic_pair(r*pairs_per_step + i), i < pairs_per_step; torch.manual_seed(r) "
@@ -291,16 +363,17 @@ def main():
 
     if rank == 0 and n_gpus == 1 and not args.no_roofline:
         prof, eng, preps, active = kernel_profile(model, pairs, B)
-        S, T = preps[0].S, preps[0].T
+        S, T, n = preps[0].S, preps[0].T, preps[0].S + preps[0].K       # n: points through the MLP (landmarks + samples)
         P = eng.P
         dom = max(prof, key=prof.get)
-        # backward split by layer: bwd2 = heads (dWh + dh2: 2*768 MAC) + dW2 + dh1, bwd1 = dW1 + dh0 + dW0 (768 MAC)
-        flops = {"k_eng_fwd": FLOP_FWD_PT * S, "k_eng_bwd2": 2 * (2 * 16384 + 1536) * S,
-                 "k_eng_bwd1": 2 * (2 * 16384 + 768) * S, "k_eng_nn": FLOP_NN_PAIR * S * T,
+        nh = preps[0].desc.n_heads                                       # head rows: 6 SE3, 7 Sim3 (+768 FLOP/pt)
+        # backward split by layer: bwd2 = heads (dWh + dh2) + dW2 + dh1, bwd1 = dW1 + dh0 + dW0 (768 MAC)
+        flops = {"k_eng_fwd": (FLOP_FWD_PT + 256 * (nh - 6)) * n, "k_eng_bwd2": 2 * (2 * 16384 + 256 * nh) * n,
+                 "k_eng_bwd1": 2 * (2 * 16384 + 768) * n, "k_eng_nn": FLOP_NN_PAIR * S * T,
                  "k_eng_update": 12 * P, "k_eng_loss": 4 * (S + T)}
         ach = flops[dom] * active / (prof[dom] * 1e-3) / 1e12
         tick_ms = sum(prof.values())
-        traffic = pmc_traffic(dom, active)
+        traffic = pmc_traffic(dom, active) if args.config == "A" else None
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic,
                            "avg_launch_ms": prof[dom], "pairs_per_launch": active,
@@ -309,10 +382,10 @@ def main():
             out["roofline"]["hbm_tbps"] = traffic / (prof[dom] * 1e-3) / 1e12
             out["roofline"]["hbm_frac"] = out["roofline"]["hbm_tbps"] / 8.0
         out["kernels_ms_per_tick"] = prof
-        out["tick"] = {"ms": tick_ms, "achieved_tflops": algorithmic_flops(S, T, P) * active / (tick_ms * 1e-3) / 1e12}
-    if rank == 0 and n_gpus == 1 and not args.no_roofline:
+        out["tick"] = {"ms": tick_ms, "achieved_tflops": (algorithmic_flops(n, 0, P) + FLOP_NN_PAIR * S * T) * active / (tick_ms * 1e-3) / 1e12}
+    if rank == 0 and n_gpus == 1 and not args.no_roofline and args.config == "A":
         # accuracy on pairs NDP actually solves: 8 partial-overlap SURFACE pairs (tests/golden/F10b holds the reference's
-        # own rows: full-EPE 6.1, AccS 35.6 %, AccR 62.6 %; zero flow: EPE 13.4, AccS 0.3 %) -- not timed
+        # own rows: full-EPE 6.1, AccS 35.6 %, AccR 62.6 %; zero flow: EPE 13.4, AccS 0.8 %) -- not timed
         sp = [surface_pair(p) for p in range(8)]
         torch.manual_seed(0)
         res = model.register_batch([(a.to(dev), b.to(dev)) for a, b, _, _ in sp], slots=8, engines=1)
@@ -323,12 +396,11 @@ def main():
             acc = v if acc is None else acc + v
         out["accuracy_surface_pairs"] = dict({k: float(x / 8) for k, x in zip(mtr.keys(), acc)},
                                              reference={"full-epe": 6.12, "full-AccS": 35.6, "full-AccR": 62.6},
-                                             zero_flow={"full-epe": 13.36, "full-AccS": 0.3})
-    if rank == 0 and n_gpus == 1 and not args.no_latency:
+                                             zero_flow={"full-epe": 13.36, "full-AccS": 0.83})
+    if rank == 0 and n_gpus == 1 and not args.no_latency and args.config == "A":
         out["latency"] = latency_profile(cfg, pairs)
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        src, tgt = pairs[0]
-        out["cpu_baseline"] = cpu_baseline(cfg, src, tgt)
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and args.config == "A":
+        out["cpu_baseline"] = cpu_baseline(cfg, pairs)
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

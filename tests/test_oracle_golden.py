@@ -283,6 +283,31 @@ def test_ply_reader_reproduces_the_demo_mesh_numbers(golden):
         assert int(f.sum()) == int(g[f"mesh.{tag}.fsum"])
 
 
+def test_torch_cpu_restatement_follows_the_reference_trace(golden):
+    """oracle/ndp_torch_ref.py (the BLAS-backed baseline bench.py times beside the C port) against the reference's F4/F5
+    loss traces at two levels, and against the C oracle's warp: the same algorithm, stated on plain torch ops."""
+    from oracle import ndp_torch_ref as T
+    g = golden("F4F5_iteration")
+    for tag, lvl in (("se3aa.L0", 0), ("se3aa.L5", 5)):
+        pyr = seeded_pyramid(int(g[f"{tag}.seed"]), **VARIANTS["se3aa"])
+        d = pyr.descs[lvl]
+        x, y = torch.from_numpy(g[f"{tag}.x"]), torch.from_numpy(g[f"{tag}.y"])
+        p = T.split_level(pyr.store[lvl, :d.param_count])
+        w0 = T.level_forward(p, x, lvl).detach().numpy()
+        np.testing.assert_allclose(w0, g[f"{tag}.warp0"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(w0, O.level_fwd(cdesc(d), pyr.store[lvl, :d.param_count].numpy(), lvl, K0, g[f"{tag}.x"]),
+                                   rtol=0, atol=1e-6)
+        opt = torch.optim.Adam(p, lr=0.01)
+        losses = []
+        for _ in range(20):
+            loss = T.chamfer_l1(T.level_forward(p, x, lvl), y)
+            losses.append(loss.item())
+            opt.zero_grad(); loss.backward(); opt.step()
+        ref = g[f"{tag}.losses"]
+        assert abs(losses[0] - ref[0]) < 2e-6 * ref[0]
+        assert np.abs(np.array(losses) - ref).max() < 1e-2 * ref.max()
+
+
 # ------------------------------------------------------------------- F6/F7: early stop + end to end
 def test_F6_stop_rule_replays_reference_iteration_counts(golden):
     """Feed the reference's own loss trace to the oracle's stop rule: the per-level evaluation

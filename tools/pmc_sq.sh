@@ -21,8 +21,6 @@ out = {}
 for k, cs in sorted(acc.items()):
     row = {c: sum(v[4:]) / max(len(v[4:]), 1) for c, v in cs.items()}          # skip warm-up ticks
     row["avg_us_under_pmc"] = sum(dur[k][4:]) / max(len(dur[k][4:]), 1)
-    if row.get("GRBM_GUI_ACTIVE"):
-        row["effective_clock_ghz"] = row["GRBM_GUI_ACTIVE"] / (row["avg_us_under_pmc"] * 1e3)
     out[k] = row
 json.dump({"pairs_per_launch": int(sys.argv[3]), "kernels": out}, open(sys.argv[1].replace("pmc_sq/pmc_counter_collection.csv", "pmc_sq.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
