@@ -138,7 +138,7 @@ _SIGS = {
     "ndp_level_fwd": [DP, V, I, I, V, I, V, V, V, V, V],
     "ndp_level_bwd": [DP, V, I, I, V, I, V, V, V, V, V, V, I, I, V],
     "ndp_grad_reduce": [V, I, I, I, V, V],
-    "ndp_pyramid_fwd": [DP, I, I, V, I, V, I, V, V, V],
+    "ndp_pyramid_fwd": [DP, I, I, V, I, V, I, V, V],
     "ndp_pyramid_fwd_batch": [DP, I, I, I, ctypes.POINTER(WarpJob), I, V],
     "ndp_pair_means": [V, I, V, I, V, V],
     "ndp_nsfp_fwd": [V, V, I, V, V, V, V],

@@ -2085,7 +2085,7 @@ extern "C" int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, 
                                      const ndp_warp_job *jobs, int n_jobs, void *stream);
 
 extern "C" int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const float *params_all, int p_stride,
-                               const float *x, int n, float *x_out, float *tmp, void *stream) {
+                               const float *x, int n, float *x_out, void *stream) {
     if (int rc = check_desc(desc)) return rc;
     if (m < 0 || m > NDP_MAX_LEVELS || n < 0 || !x_out || (n > 0 && !x)) return fail(NDP_E_INVALID, "ndp_pyramid_fwd: bad arguments");
     if (n == 0) return 0;
@@ -2093,7 +2093,6 @@ extern "C" int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const 
         HIP_TRY(hipMemcpyAsync(x_out, x, sizeof(float) * 3 * (size_t)n, hipMemcpyDeviceToDevice, (hipStream_t)stream), "memcpy");
         return 0;
     }
-    (void)tmp;                       // kept in the signature for ABI stability; the fused kernel needs no scratch
     ndp_warp_job job;
     memset(&job, 0, sizeof job);
     job.params = params_all; job.x = x; job.x_out = x_out; job.n = n;

@@ -84,7 +84,7 @@ def pyramid_fwd(desc: LayerDesc, m, k0, store, x):
     out = torch.empty_like(x)
     cd = desc.c_struct()
     N.check(N.lib().ndp_pyramid_fwd(ctypes.byref(cd), int(m), int(k0), _p(store), store.stride(0), _p(x), x.shape[0],
-                                    _p(out), None, N.stream_ptr(x.device)), "ndp_pyramid_fwd")
+                                    _p(out), N.stream_ptr(x.device)), "ndp_pyramid_fwd")
     return out
 
 

@@ -65,10 +65,9 @@ int ndp_grad_reduce(const float *grads_part, int n_part, int p_stride, int P, fl
 
 /* Whole pyramid forward, levels 0..m-1 (Deformation_Pyramid.warp, nets.py:36-48; the final
  * inference warp of registration.py:254-255).  params_all: level l at params_all + l*p_stride.
- * desc->nonrigidity = 1 means "every level but the first carries the gate" (nets.py:26).
- * tmp: unused (kept for ABI stability; may be NULL).                                              */
+ * desc->nonrigidity = 1 means "every level but the first carries the gate" (nets.py:26).        */
 int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const float *params_all, int p_stride,
-                    const float *x, int n, float *x_out, float *tmp, void *stream);
+                    const float *x, int n, float *x_out, void *stream);
 
 /* Batched, single-launch form of the final inference warp: every job is one cloud pushed through all m
  * levels inside ONE kernel (grid = tiles x jobs; a workgroup keeps its 64 points in LDS from level to
