@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libndp_hip.so")
 SOURCES = ["ndp_kernels.hip"]
-HEADERS = ["ndp_device.h", os.path.join("..", "..", "include", "ndp_hip.h"), os.path.join("..", "..", "include", "ndp_types.h")]
+HEADERS = ["ndp_device.h", "ndp_nerfies.inc", os.path.join("..", "..", "include", "ndp_hip.h"), os.path.join("..", "..", "include", "ndp_types.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 NDP_MAX_LEVELS = 16
@@ -143,6 +143,8 @@ _SIGS = {
     "ndp_pair_means": [V, I, V, I, V, V],
     "ndp_nsfp_fwd": [V, V, I, V, V, V, V],
     "ndp_nsfp_bwd": [V, V, I, V, V, V, V, I, I, V],
+    "ndp_nerfies_fwd": [V, V, I, c_float_p, V, V, V, V, I, V, V, V, V],
+    "ndp_nerfies_bwd": [V, V, I, V, V, V, V, V, V, I, I, V],
     "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],
     "ndp_chamfer_nn_onepass": [V, I, V, I, V, V, V, V, V, V],
     "ndp_chamfer_l1_bwd": [V, I, V, I, F, V, V, V, V, V, V, V],

@@ -2363,3 +2363,5 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
     HIP_TRY(err, "ndp_engine_run_timed sync");
     return 0;
 }
+
+#include "ndp_nerfies.inc"

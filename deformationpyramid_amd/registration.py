@@ -153,7 +153,11 @@ class Registration:
             from .nsfp import optimize_neural_SFlow
             kwargs.pop("timer", None)
             return optimize_neural_SFlow(self, **kwargs)
-        # Sinkhorn / ED / Nerfies are comparison baselines outside this path
+        if self.deformation_model == "Nerfies":                   # registration.py:118-119 -> (warped, None)
+            from .nerfies import optimize_Nerfies
+            kwargs.pop("timer", None)
+            return optimize_Nerfies(self, **kwargs)
+        # Sinkhorn / ED are comparison baselines outside this path
         raise KeyError(self.deformation_model)
 
     def optimize_deformation_pyramid(self, visualize=False, timer=None):

@@ -16,8 +16,8 @@ then `compute_flow_metrics` averaged by `AverageMeter`, then the timer report.  
 * under `torchrun` (WORLD_SIZE > 1) the pairs of each benchmark are sharded over the ranks, one GPU per rank
   (`parallel.shard_range`), and the per-metric sums are combined by ONE all-reduce (RCCL; `NDP_BENCH_BACKEND=gloo` for a
   rehearsal on a box with one GPU) -- BASELINE.json config 3, "4DMatch-F full split batched across 8 GPUs";
-* `deformation_model: NDP` and the `NSFP` baseline (config/baselines/NSFP.yaml) are served; the other models are
-  comparison baselines outside the scope.
+* `deformation_model: NDP` and the `NSFP` / `Nerfies` baselines (config/baselines/*.yaml) are served; the other models
+  are comparison baselines outside the scope.
 """
 import argparse
 import glob
@@ -121,7 +121,7 @@ def main():
     world, rank, local_rank, backend = dist_setup()
     setup_seed(rank)                                                        # once per process, as upstream (seed 0 on one GPU)
     config = load_config(args.config, make_dirs=rank == 0, device=local_rank)
-    if config.deformation_model not in ("NDP", "NSFP"):
+    if config.deformation_model not in ("NDP", "NSFP", "Nerfies"):
         raise KeyError(config.deformation_model)
     model = Registration(config)
     timer = Timers()
@@ -136,7 +136,7 @@ def main():
         lo, hi = shard_range(len(data), rank, world)                        # this rank's pairs
         items = [data[i] for i in range(lo, hi)]
         n_total = len(data)
-        if config.deformation_model == "NSFP":                              # eval_nolearned.py:97-110
+        if config.deformation_model in ("NSFP", "Nerfies"):                 # eval_nolearned.py:97-110
             flows = []
             for src, tgt, _, _ in items:
                 model.load_pcds(src, tgt)

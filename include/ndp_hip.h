@@ -104,6 +104,22 @@ int ndp_nsfp_fwd(const float *params, const float *x, int n, float *x_out, float
 int ndp_nsfp_bwd(const float *params, const float *x, int n, float *act, const float *g,
                  float *dO_work, float *grads_part, int n_part, int p_stride, void *stream);
 
+/* ---- Nerfies baseline, SURVEY section 8 f3 (second half) ------------------------------------------------------------
+ * Nerfies_Deformation.forward (nets.py:187-253): windowed 39-wide posenc -> 39->128 -> six 128x128 ReLU layers -> w / v
+ * heads -> SE(3) exponential warp, plus the per-point Jacobian d warp / d x (carried forward as three tangent rows per
+ * point: every buffer holds four planes [primal | d/dx0 | d/dx1 | d/dx2] of cap = n rounded up to 64 rows) and
+ * reg = mean_p log(max(sigma_max(J_p), 1e-6))^2 (loss.py:373-379, per point in double).  Parameter layout:
+ * [W_in 128x39 | b_in 128 | (W_l 128x128 | b_l 128) l=1..6 | W_h 6x128 (w rows, v rows) | b_h 6], P = 104 966.
+ *   window6: HOST array of the six annealing weights of the iteration (nets.py:223-225)
+ *   act: [save ? 7 : 2][4 cap][128] activation planes; pe: [cap][40]; heads: [4 cap][8]; work: [cap] doubles.           */
+int ndp_nerfies_fwd(const float *params, const float *x, int n, const float *window6, float *x_out, float *J,
+                    float *reg, float *act, int save, float *pe, float *heads, double *work, void *stream);
+/* Gradient of a scalar loss wrt all parameters given g = dL/d(x_out) [n][3]; the regulariser carries none upstream (its
+ * Jacobian is built with create_graph=False).  act (save = 1) is consumed.  dO_work [cap][16]; grads_part
+ * [n_part][p_stride] partials for ndp_grad_reduce.                                                                     */
+int ndp_nerfies_bwd(const float *params, const float *x, int n, float *act, const float *pe, const float *heads,
+                    const float *g, float *dO_work, float *grads_part, int n_part, int p_stride, void *stream);
+
 /* Exact brute-force 1-NN in both directions (pytorch3d knn_points K=1 as called at loss.py:177-178):
  * d2x[i] = min_j |x_i - y_j|^2 (fma chain over x,y,z), idx_x[i] = lowest argmin; same for y->x.  */
 int ndp_chamfer_nn_fwd(const float *x, int S, const float *y, int T,

@@ -726,6 +726,83 @@ def F12_nsfp(nets, loss_mod, reg_mod, EasyDict, **_):
     save("F12_nsfp", **out)
 
 
+def F14_nerfies(nets, loss_mod, reg_mod, EasyDict, **_):
+    """Nerfies baseline (second half): Nerfies_Deformation init / windowed posenc / SE(3) exp warp /
+    per-point Jacobian / log-singular-value regulariser / parameter gradients of cd + 0.001 reg at two annealing stages,
+    and optimize_Nerfies end to end on a small pair with every evaluated loss recorded."""
+    out = {}
+    torch.manual_seed(23)
+    net = nets.Nerfies_Deformation(max_iter=5000)
+    names = [k for k, _ in net.named_parameters()]
+    out["names"] = np.array(names)
+    for k, v in net.named_parameters():
+        a = v.detach().numpy()
+        out[f"init.{k}.sum"] = np.float64(a.astype(np.float64).sum())
+        out[f"init.{k}.abs"] = np.float64(np.abs(a.astype(np.float64)).sum())
+        out[f"init.{k}.head"] = a.reshape(-1)[:8].copy()
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(200, 3, generator=g) - 0.5
+    y = (torch.rand(180, 3, generator=g) - 0.5) * 1.1 + 0.03
+    out["fb.x"], out["fb.y"] = x.numpy(), y.numpy()
+    for it in (0, 700, 2999):
+        for v in net.parameters():
+            v.grad = None
+        warped, J = net(x, iter=it)
+        reg = loss_mod.nerfies_regularization(J)
+        cd = loss_mod.compute_truncated_chamfer_distance(warped[None], y[None], trunc=1e+9)
+        loss = cd + 0.001 * reg
+        loss.backward()
+        out[f"fb{it}.pe"] = net.posenc(x, it).detach().numpy()
+        out[f"fb{it}.warped"] = warped.detach().numpy()
+        out[f"fb{it}.J"] = J.detach().numpy()
+        out[f"fb{it}.reg"] = np.float64(reg.item())
+        out[f"fb{it}.cd"] = np.float64(cd.item())
+        out[f"fb{it}.loss"] = np.float64(loss.item())
+        for k, v in net.named_parameters():
+            gr = v.grad.numpy()
+            out[f"fb{it}.grad.{k}"] = gr.copy() if gr.size <= 4992 else gr.reshape(-1)[::37].copy()
+            out[f"fb{it}.gsum.{k}"] = np.float64(gr.astype(np.float64).sum())
+            out[f"fb{it}.gabs.{k}"] = np.float64(np.abs(gr.astype(np.float64)).sum())
+        # upstream builds J with torch.autograd.functional.jacobian(create_graph=False): it is a constant for autograd, so
+        # the regulariser moves the loss VALUE (and the stop rule) but contributes no parameter gradient
+        out[f"fb{it}.J_requires_grad"] = np.int64(int(J.requires_grad))
+        print(f"  iter {it}: cd {cd.item():.6f} reg {reg.item():.6e}", flush=True)
+    # end to end
+    src, tgt, flow_gt, overlap = synthetic_pair(9, n_total=2048)
+    cfg = EasyDict(dict(deformation_model="Nerfies", device=torch.device("cpu"), iters=40, lr=0.01, max_break_count=70,
+                        break_threshold_ratio=0.001, samples=256))
+    trace = []
+    orig_cd, orig_reg = reg_mod.compute_truncated_chamfer_distance, reg_mod.nerfies_regularization
+
+    def cd_hook(*a, **k):
+        v = orig_cd(*a, **k)
+        trace.append([v.item(), None])
+        return v
+
+    def reg_hook(*a, **k):
+        v = orig_reg(*a, **k)
+        trace_reg.append(v.item())
+        return v
+
+    trace_reg = []
+    reg_mod.compute_truncated_chamfer_distance = cd_hook
+    reg_mod.nerfies_regularization = reg_hook
+    try:
+        torch.manual_seed(3)
+        model = reg_mod.Registration(cfg)
+        model.load_pcds(src.numpy(), tgt.numpy())
+        warped, _ = model.register()
+    finally:
+        reg_mod.compute_truncated_chamfer_distance = orig_cd
+        reg_mod.nerfies_regularization = orig_reg
+    out["e2e.src"], out["e2e.tgt"] = src.numpy(), tgt.numpy()
+    out["e2e.warped"] = warped.detach().numpy()
+    out["e2e.cd_trace"] = np.array([t[0] for t in trace], dtype=np.float64)
+    out["e2e.reg_trace"] = np.array(trace_reg, dtype=np.float64)
+    out["e2e.seed"] = np.int64(3)
+    save("F14_nerfies", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -743,7 +820,7 @@ def main():
         "F7": F7_end_to_end, "F8": F8_metrics, "F9": F9_landmarks, "F9b": F9b_lndp_end_to_end,
         "F9c": F9c_mixed_landmark_chamfer,
         "F10": F10_benchmark, "F10b": F10b_surface_benchmark, "F11": F11_nonrigidity, "F12": F12_nsfp,
-        "F13": F13_shape_transfer,
+        "F13": F13_shape_transfer, "F14": F14_nerfies,
     }
     only = [s for s in args.only.split(",") if s]
     for k, fn in todo.items():
