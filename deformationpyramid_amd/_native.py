@@ -147,7 +147,8 @@ _SIGS = {
     "ndp_nerfies_bwd": [V, V, I, V, V, V, V, V, V, I, I, V],
     "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],
     "ndp_chamfer_nn_onepass": [V, I, V, I, V, V, V, V, V, V],
-    "ndp_chamfer_l1_bwd": [V, I, V, I, F, V, V, V, V, V, V, V],
+    "ndp_chamfer_l1_bwd": [V, I, V, I, F, V, V, V, V, V, V, I, V],
+    "ndp_flow_metrics": [V, V, V, I, V, V],
     "ndp_landmark_mse_fwd_bwd": [V, V, I, V, V, V],
     "ndp_adam_step": [V, V, V, V, I, F, F, F, F, F, F, V],
     "ndp_engine_run": [ctypes.POINTER(Engine), I, I, V],

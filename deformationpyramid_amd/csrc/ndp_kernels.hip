@@ -1058,12 +1058,14 @@ __device__ __forceinline__ float sq_sum(const float *x, const float *tt, int K, 
 
 extern "C" __global__ void __launch_bounds__(256)
 k_chamfer_bwd(const float *x, int S, const float *y, int T, float trunc, const float *d2x, const int *idx_x,
-              const float *d2y, const int *idx_y, float *loss, float *gx) {
+              const float *d2y, const int *idx_y, float *loss, float *gx, int point_sum) {
     __shared__ float scratch[256];
+    // point_reduction (loss.py:233-235): "mean" divides each direction's sum by its point count, "sum" does not
+    const float Sdiv = point_sum ? 1.0f : (float)S, Tdiv = point_sum ? 1.0f : (float)T;
     if (blockIdx.x == 0) {
         const float sx = l1_sum(d2x, S, trunc, scratch);
         const float sy = l1_sum(d2y, T, trunc, scratch);
-        if (threadIdx.x == 0) loss[0] = sx / (float)S + sy / (float)T;
+        if (threadIdx.x == 0) loss[0] = sx / Sdiv + sy / Tdiv;
     }
     if (!gx) return;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1072,13 +1074,13 @@ k_chamfer_bwd(const float *x, int S, const float *y, int T, float trunc, const f
     float g[3] = {0.f, 0.f, 0.f};
     if (!(d2x[i] >= trunc)) {
         const float *yy = y + 3 * idx_x[i];
-        const float inv = 1.0f / ((float)S * sqrtf(d2x[i]));
+        const float inv = 1.0f / (Sdiv * sqrtf(d2x[i]));
 #pragma unroll
         for (int a = 0; a < 3; ++a) g[a] = (xi[a] - yy[a]) * inv;
     }
     for (int j = 0; j < T; ++j) {           // ascending j: same order as the oracle / the CPU reference
         if (idx_y[j] == i && !(d2y[j] >= trunc)) {
-            const float inv = 1.0f / ((float)T * sqrtf(d2y[j]));
+            const float inv = 1.0f / (Tdiv * sqrtf(d2y[j]));
 #pragma unroll
             for (int a = 0; a < 3; ++a) g[a] = fmaf(xi[a] - y[3 * j + a], inv, g[a]);
         }
@@ -2248,9 +2250,9 @@ extern "C" int ndp_chamfer_nn_fwd(const float *x, int S, const float *y, int T,
 
 extern "C" int ndp_chamfer_l1_bwd(const float *x, int S, const float *y, int T, float trunc,
                                   const float *d2x, const int *idx_x, const float *d2y, const int *idx_y,
-                                  float *loss, float *gx, void *stream) {
+                                  float *loss, float *gx, int point_sum, void *stream) {
     if (S <= 0 || T <= 0 || !x || !y || !d2x || !idx_x || !d2y || !idx_y || !loss) return fail(NDP_E_INVALID, "ndp_chamfer_l1_bwd: bad arguments");
-    hipLaunchKernelGGL(k_chamfer_bwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, S, y, T, trunc, d2x, idx_x, d2y, idx_y, loss, gx);
+    hipLaunchKernelGGL(k_chamfer_bwd, dim3((S + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, S, y, T, trunc, d2x, idx_x, d2y, idx_y, loss, gx, point_sum ? 1 : 0);
     HIP_TRY(hipGetLastError(), "k_chamfer_bwd launch");
     return 0;
 }
@@ -2361,6 +2363,52 @@ extern "C" int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks,
     delete[] ev;
     if (rc) return rc;
     HIP_TRY(err, "ndp_engine_run_timed sync");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Scene-flow metrics on the device (loss.py:382-403, 431-471): per subset {all, overlap, ~overlap} the sum of the end-point
+// errors and the counts behind AccS / AccR / Outlier.  One workgroup, fixed order, double accumulation.
+// out[3][5] doubles: {sum err, #(err < .025 | rel < .025), #(err < .05 | rel < .05), #(rel > .3), #points}.
+// ------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(1024)
+k_flow_metrics(const float *flow, const float *gt, const unsigned char *overlap, int n, double *out) {
+    __shared__ double red[1024];
+    double acc[3][5];
+    for (int s = 0; s < 3; ++s)
+        for (int k = 0; k < 5; ++k) acc[s][k] = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float d0 = flow[3 * (size_t)i] - gt[3 * (size_t)i], d1 = flow[3 * (size_t)i + 1] - gt[3 * (size_t)i + 1],
+                    d2 = flow[3 * (size_t)i + 2] - gt[3 * (size_t)i + 2];
+        const float g0 = gt[3 * (size_t)i], g1 = gt[3 * (size_t)i + 1], g2 = gt[3 * (size_t)i + 2];
+        const float err = sqrtf((d0 * d0 + d1 * d1) + d2 * d2);
+        const float rel = err / (sqrtf((g0 * g0 + g1 * g1) + g2 * g2) + 1e-20f);
+        const double v[5] = {(double)err, (err < 0.025f || rel < 0.025f) ? 1.0 : 0.0, (err < 0.05f || rel < 0.05f) ? 1.0 : 0.0,
+                             rel > 0.3f ? 1.0 : 0.0, 1.0};
+        const int sub = overlap ? (overlap[i] ? 1 : 2) : 0;
+        for (int k = 0; k < 5; ++k) {
+            acc[0][k] += v[k];
+            if (sub == 1) acc[1][k] += v[k];
+            if (sub == 2) acc[2][k] += v[k];
+        }
+    }
+    for (int s = 0; s < 3; ++s)
+        for (int k = 0; k < 5; ++k) {
+            red[threadIdx.x] = acc[s][k];
+            __syncthreads();
+            for (int d = 512; d > 0; d >>= 1) {
+                if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) out[5 * s + k] = red[0];
+            __syncthreads();
+        }
+}
+
+extern "C" int ndp_flow_metrics(const float *flow, const float *flow_gt, const unsigned char *overlap, int n, double *out15, void *stream) {
+    if (n < 0 || !out15 || (n > 0 && (!flow || !flow_gt))) return fail(NDP_E_INVALID, "ndp_flow_metrics: bad arguments");
+    hipLaunchKernelGGL(k_flow_metrics, dim3(1), dim3(1024), 0, (hipStream_t)stream, flow, flow_gt, overlap, n, out15);
+    HIP_TRY(hipGetLastError(), "k_flow_metrics launch");
     return 0;
 }
 

@@ -35,8 +35,6 @@ def compute_truncated_chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_n
         raise ValueError('batch_reduction must be one of ["mean", "sum"] or None')
     if point_reduction not in ["mean", "sum"]:
         raise ValueError('point_reduction must be one of ["mean", "sum"]')
-    if point_reduction == "sum":
-        raise NotImplementedError('point_reduction="sum" is used by no caller of the NDP path and is not implemented')
     if x_normals is not None or y_normals is not None:
         raise NotImplementedError("normals are not used by the NDP path and are not supported")
     xl = _lengths(x, x_lengths, "x")
@@ -57,7 +55,7 @@ def compute_truncated_chamfer_distance(x, y, x_lengths=None, y_lengths=None, x_n
     per_batch = []
     for b in range(N):
         xb, yb = x[b, :xl[b]], y[b, :yl[b]]
-        v = ops.chamfer_distance(xb, yb, trunc)                  # sum_x/len_x + sum_y/len_y (loss.py:233-235)
+        v = ops.chamfer_distance(xb, yb, trunc, point_sum=point_reduction == "sum")   # sum_x[/len_x] + sum_y[/len_y] (loss.py:233-235)
         if weights is not None:
             v = v * weights[b]
         per_batch.append(v)
@@ -86,7 +84,24 @@ def scene_flow_metrics(pred, labels, strict=0.025, relax=0.05):
     return epe * 100, acc_s * 100, acc_r * 100, outlier * 100
 
 
+def _metrics_on_device(flow, flow_gt, overlap):
+    sums = ops.flow_metrics(flow.detach().float().contiguous(), flow_gt.detach().float().contiguous(), overlap)
+    info = {}
+    for tag, row in zip(("full", "vis", "occ") if overlap is not None else ("full",), sums):
+        cnt = row[4].item()
+        if cnt == 0:                                              # upstream: mean over an empty selection
+            vals = [float("nan")] * 4
+        else:
+            vals = [float(torch.tensor(row[0].item() / cnt, dtype=torch.float32)) * 100] + [100.0 * row[k].item() / cnt for k in (1, 2, 3)]
+        info.update({f"{tag}-epe": vals[0], f"{tag}-AccS": vals[1], f"{tag}-AccR": vals[2], f"{tag}-outlier": vals[3]})
+    return info
+
+
 def compute_flow_metrics(flow, flow_gt, overlap=None):
+    """loss.py:431-471.  GPU tensors are reduced on the device (k_flow_metrics: one launch, 15 sums back); CPU tensors take
+    the torch path upstream takes."""
+    if torch.is_tensor(flow) and flow.is_cuda and flow.shape[0] > 0:
+        return _metrics_on_device(flow, flow_gt.to(flow.device), overlap)
     info = {}
     subsets = [("full", None)]
     if overlap is not None:

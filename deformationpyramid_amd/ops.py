@@ -153,15 +153,15 @@ def chamfer_nn_onepass(x, y):
     return d2x, ix, d2y, iy
 
 
-def chamfer_l1(x, y, trunc, nn=None, want_grad=True):
-    """-> (loss [1], gx [S,3] | None, nn tuple)."""
+def chamfer_l1(x, y, trunc, nn=None, want_grad=True, point_sum=False):
+    """-> (loss [1], gx [S,3] | None, nn tuple).  point_sum: point_reduction="sum" of loss.py:233-235."""
     if nn is None:
         nn = chamfer_nn(x, y)
     d2x, ix, d2y, iy = nn
     loss = torch.empty(1, device=x.device)
     gx = torch.empty_like(x) if want_grad else None
     N.check(N.lib().ndp_chamfer_l1_bwd(_p(x), x.shape[0], _p(y), y.shape[0], float(trunc), _p(d2x), _p(ix), _p(d2y),
-                                       _p(iy), _p(loss), _p(gx), N.stream_ptr(x.device)), "ndp_chamfer_l1_bwd")
+                                       _p(iy), _p(loss), _p(gx), 1 if point_sum else 0, N.stream_ptr(x.device)), "ndp_chamfer_l1_bwd")
     return loss, gx, nn
 
 
@@ -239,18 +239,31 @@ def level_warp(layer, x):
 
 class _ChamferFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, y, trunc):
+    def forward(ctx, x, y, trunc, point_sum=False):
         xd, yd = x.detach().contiguous(), y.detach().contiguous()
-        loss, gx, _ = chamfer_l1(xd, yd, trunc, want_grad=x.requires_grad)
+        loss, gx, _ = chamfer_l1(xd, yd, trunc, want_grad=x.requires_grad, point_sum=point_sum)
         ctx.save_for_backward(gx if gx is not None else torch.empty(0, device=x.device))
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         (gx,) = ctx.saved_tensors
-        return (gx * g if gx.numel() else None), None, None
+        return (gx * g if gx.numel() else None), None, None, None
 
 
-def chamfer_distance(x, y, trunc):
+def chamfer_distance(x, y, trunc, point_sum=False):
     """Differentiable (wrt x) truncated L1 Chamfer of two [n,3] clouds."""
-    return _ChamferFn.apply(x, y, float(trunc))
+    return _ChamferFn.apply(x, y, float(trunc), bool(point_sum))
+
+
+def flow_metrics(flow, flow_gt, overlap=None):
+    """Device-side sums behind compute_flow_metrics -> [3,5] float64 on the host: per subset {all, overlap, ~overlap}
+    {sum err, #AccS, #AccR, #outlier, #points}."""
+    _chk(flow, "flow"); _chk(flow_gt, "flow_gt")
+    n = flow.shape[0]
+    ov = None
+    if overlap is not None:
+        ov = overlap.to(device=flow.device, dtype=torch.uint8).contiguous()
+    out = torch.empty(15, device=flow.device, dtype=torch.float64)
+    N.check(N.lib().ndp_flow_metrics(_p(flow), _p(flow_gt), _p(ov), n, _p(out), N.stream_ptr(flow.device)), "ndp_flow_metrics")
+    return out.cpu().view(3, 5)

@@ -134,11 +134,18 @@ int ndp_chamfer_nn_onepass(const float *x, int S, const float *y, int T, float *
                            int *idx_y, float *ws_row, void *stream);
 
 /* Truncated L1 Chamfer value and gradient from the NN result (loss.py:185-258 and its autograd):
- * loss[0] = sum_i sqrt(d2x_i)[d2x_i<trunc]/S + sum_j sqrt(d2y_j)[d2y_j<trunc]/T ;
+ * loss[0] = sum_i sqrt(d2x_i)[d2x_i<trunc]/S + sum_j sqrt(d2y_j)[d2y_j<trunc]/T   (point_sum != 0: without the /S, /T --
+ * point_reduction="sum", loss.py:233-235) ;
  * gx [S][3] = dloss/dx (contributions of y_j -> x_i added in ascending j).                      */
 int ndp_chamfer_l1_bwd(const float *x, int S, const float *y, int T, float trunc,
                        const float *d2x, const int *idx_x, const float *d2y, const int *idx_y,
-                       float *loss, float *gx, void *stream);
+                       float *loss, float *gx, int point_sum, void *stream);
+
+/* compute_flow_metrics / scene_flow_metrics (loss.py:382-403, 431-471) on the device: flow, flow_gt [n][3]; overlap [n]
+ * bytes (0 / 1) or NULL.  out15 (device, 3 x 5 doubles), per subset {all, overlap, not overlap}:
+ * {sum of end-point errors, #AccS hits, #AccR hits, #outliers, #points}; the caller divides (an empty subset gives NaN
+ * like upstream's mean over nothing).                                                                                 */
+int ndp_flow_metrics(const float *flow, const float *flow_gt, const unsigned char *overlap, int n, double *out15, void *stream);
 
 /* Landmark loss mean_k |x_k - t_k|^2 and gradient (registration.py:201-203). */
 int ndp_landmark_mse_fwd_bwd(const float *x, const float *t, int K, float *loss, float *gx, void *stream);

@@ -311,6 +311,41 @@ def test_F13_shape_transfer_on_the_engine_against_the_reference(dev, golden):
     assert got.shape == (24856, 3) and np.abs(got - g["warped_vert"]).max() < 1e-4
 
 
+def test_flow_metrics_on_the_device_match_the_reference_golden(dev, golden):
+    """compute_flow_metrics on GPU tensors (k_flow_metrics: one launch, 15 sums) against golden F8 captured from the
+    reference, against the torch-CPU path, and the NaN of an empty subset (loss.py:461)."""
+    from deformationpyramid_amd.loss import compute_flow_metrics
+    g = golden("F8_metrics")
+    flow, gt, ov = torch.from_numpy(g["flow"]), torch.from_numpy(g["flow_gt"]), torch.from_numpy(g["overlap"])
+    got = compute_flow_metrics(flow.to(dev), gt.to(dev), ov.to(dev))
+    cpu = compute_flow_metrics(flow, gt, ov)
+    for k, v in zip(g["keys"], g["vals"]):
+        assert abs(got[str(k)] - float(v)) < 1e-4 * max(1.0, abs(float(v))), k
+        assert abs(got[str(k)] - cpu[str(k)]) < 1e-4 * max(1.0, abs(cpu[str(k)])), k
+    only_full = compute_flow_metrics(flow.to(dev), gt.to(dev))
+    assert list(only_full) == ["full-epe", "full-AccS", "full-AccR", "full-outlier"] and only_full["full-epe"] == got["full-epe"]
+    empty = compute_flow_metrics(flow.to(dev), gt.to(dev), torch.ones_like(ov).to(dev))
+    assert np.isnan(empty["occ-epe"]) and empty["vis-epe"] == got["full-epe"]
+
+
+def test_chamfer_point_reduction_sum(dev):
+    """point_reduction="sum" (loss.py:233-235): the two directions' sums without the division by their point counts --
+    value and gradient against a plain torch statement of the same formula."""
+    from deformationpyramid_amd.loss import compute_truncated_chamfer_distance
+    x, y = cloud(300, 5), cloud(257, 6) * 1.1 + 0.02
+    xr = x.clone().requires_grad_(True)
+    dx = ((xr[:, None] - y[None]) ** 2).sum(-1)
+    ref = (dx.min(1)[0].sqrt().sum() + dx.min(0)[0].sqrt().sum())
+    ref.backward()
+    xg = x.to(dev).requires_grad_(True)
+    got = compute_truncated_chamfer_distance(xg[None], y.to(dev)[None], trunc=1e9, point_reduction="sum")
+    got.backward()
+    assert abs(got.item() - ref.item()) < 1e-5 * ref.item()
+    assert (xg.grad.cpu() - xr.grad).abs().max().item() < 1e-4
+    mean = compute_truncated_chamfer_distance(x.to(dev)[None], y.to(dev)[None], trunc=1e9)
+    assert mean.item() < got.item() / 200
+
+
 def test_engine_is_deterministic_and_G_independent_in_loss(dev):
     e1, s1, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=2)
     e2, s2, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=2)
