@@ -383,14 +383,19 @@ __device__ __forceinline__ void level_fwd_body(const HeadCfg &hc, const LevelJob
 struct WarpJobs {
     ndp_warp_job j[NDP_MAX_WARP_JOBS];
 };
+// A workgroup carries TWO 64-point tiles through all m levels (the two posenc / point sets of the LDS carve): the 135 KB of
+// a level's weights are pulled from L2 once per 128 points instead of once per 64 -- the weight prologue was half of the
+// kernel -- and the posenc of the second tile overlaps the warp of the first exactly as in the level kernel.
+#define NDP_PYR_TILES 2
 extern "C" __global__ void __launch_bounds__(256, 2)
 k_pyramid_fwd(ndp_layer_desc desc, int m, int k0, int p_stride, WarpJobs jobs) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const ndp_warp_job jb = jobs.j[blockIdx.y];
-    const int base = blockIdx.x * NDP_TILE;
-    if (base >= jb.n) return;
+    const int base0 = blockIdx.x * NDP_TILE * NDP_PYR_TILES;
+    if (base0 >= jb.n) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     float *pe = sm + L_PE, *xs = sm + L_XS, *ho = sm + L_HO;
+    const bool two = base0 + NDP_TILE < jb.n;                      // the second tile holds points
     TileIO io;
     io.act = nullptr; io.heads = nullptr; io.nonrig = nullptr; io.n = jb.n; io.plane = 0;
     io.x_in = jb.x; io.shift_in = jb.shift_in;
@@ -400,14 +405,24 @@ k_pyramid_fwd(ndp_layer_desc desc, int m, int k0, int p_stride, WarpJobs jobs) {
         fwd_load_weights(hc, jb.params + (size_t)l * p_stride, sm, fw);
         io.x_out = l == m - 1 ? jb.x_out : nullptr;
         io.shift_out = l == m - 1 ? jb.shift_out : nullptr;
+        const float freq = ldexpf(1.0f, l + 1 + k0);
         if (wv > 0) {
-            const float xa = l == 0 ? fwd_fetch_x(io, base, lane, wv - 1) : xs[4 * lane + wv - 1];
-            fwd_posenc(xa, ldexpf(1.0f, l + 1 + k0), lane, wv - 1, pe, xs, l == 0);
+            const float xa = l == 0 ? fwd_fetch_x(io, base0, lane, wv - 1) : xs[4 * lane + wv - 1];
+            fwd_posenc(xa, freq, lane, wv - 1, pe, xs, l == 0);
         }
         __syncthreads();
-        fwd_tile_core(hc, fw, io, base, sm, pe);
-        if (wv == 0) fwd_warp(hc, io, base, lane, ho, pe, xs);
+        fwd_tile_core(hc, fw, io, base0, sm, pe);
+        if (wv == 0) fwd_warp(hc, io, base0, lane, ho, pe, xs);
+        else if (two) {                                             // second tile's encoding while wave 0 warps the first
+            const float xa = l == 0 ? fwd_fetch_x(io, base0 + NDP_TILE, lane, wv - 1) : xs[64 * 4 + 4 * lane + wv - 1];
+            fwd_posenc(xa, freq, lane, wv - 1, pe + 64 * 9, xs + 64 * 4, l == 0);
+        }
         __syncthreads();
+        if (two) {
+            fwd_tile_core(hc, fw, io, base0 + NDP_TILE, sm, pe + 64 * 9);
+            if (wv == 0) fwd_warp(hc, io, base0 + NDP_TILE, lane, ho, pe + 64 * 9, xs + 64 * 4);
+            __syncthreads();
+        }
     }
 }
 
@@ -2117,7 +2132,7 @@ extern "C" int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, 
             if (!aligned16(q.params)) return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch: params must be 16-byte aligned");
             if (q.n == 0) continue;
             wj.j[cnt++] = q;
-            const int tiles = (q.n + NDP_TILE - 1) / NDP_TILE;
+            const int tiles = (q.n + NDP_TILE * NDP_PYR_TILES - 1) / (NDP_TILE * NDP_PYR_TILES);   // workgroups of this cloud
             if (tiles > max_tiles) max_tiles = tiles;
         }
         if (!cnt) continue;
