@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libndp_hip.so")
 SOURCES = ["ndp_kernels.hip"]
-HEADERS = ["ndp_device.h", "ndp_nerfies.inc", os.path.join("..", "..", "include", "ndp_hip.h"), os.path.join("..", "..", "include", "ndp_types.h")]
+HEADERS = ["ndp_device.h", "ndp_nerfies.inc", "ndp_ed.inc", os.path.join("..", "..", "include", "ndp_hip.h"), os.path.join("..", "..", "include", "ndp_types.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 NDP_MAX_LEVELS = 16
@@ -143,6 +143,9 @@ _SIGS = {
     "ndp_pair_means": [V, I, V, I, V, V],
     "ndp_nsfp_fwd": [V, V, I, V, V, V, V],
     "ndp_nsfp_bwd": [V, V, I, V, V, V, V, I, I, V],
+    "ndp_ed_warp": [V, I, V, V, V, I, V, V, V, V, V],
+    "ndp_ed_arap": [V, I, V, V, V, V, I, V, V],
+    "ndp_ed_grad": [V, I, V, V, V, V, I, V, V, V, V, V, I, F, V, V],
     "ndp_nerfies_fwd": [V, V, I, c_float_p, V, V, V, V, I, V, V, V, V],
     "ndp_nerfies_bwd": [V, V, I, V, V, V, V, V, V, I, I, V],
     "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],
@@ -205,24 +208,57 @@ class DrawOp(ctypes.Structure):
     _fields_ = [("n", ctypes.c_longlong), ("lo", ctypes.c_float), ("hi", ctypes.c_float), ("offset", ctypes.c_longlong)]
 
 
+HOST_SOURCES = [HOST_SOURCE, os.path.join(CSRC, "ndp_graph.cpp")]      # RNG replay; embedded-deformation graph builder
+
+
+def _host_id():
+    import hashlib
+    h = hashlib.sha256()
+    for src in HOST_SOURCES:
+        with open(src, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def build_host(force=False):
-    if force or not os.path.exists(HOST_LIBPATH) or os.path.getmtime(HOST_LIBPATH) < os.path.getmtime(HOST_SOURCE):
+    """g++ -> deformationpyramid_amd/lib/libndp_host.so; rebuilt when the digest of its sources changes (the digest sits
+    next to the library)."""
+    stamp = HOST_LIBPATH + ".id"
+    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+    if force or not os.path.exists(HOST_LIBPATH) or have != _host_id():
+        import fcntl
         os.makedirs(LIBDIR, exist_ok=True)
-        tmp = f"{HOST_LIBPATH}.{os.getpid()}.tmp"
-        subprocess.check_call(["g++", "-O3", "-std=c++17", "-ffp-contract=off", "-mfma", "-fPIC", "-shared",
-                               "-o", tmp, HOST_SOURCE])
-        os.replace(tmp, HOST_LIBPATH)
+        with open(os.path.join(LIBDIR, ".build_host.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            tmp = f"{HOST_LIBPATH}.{os.getpid()}.tmp"
+            subprocess.check_call(["g++", "-O3", "-std=c++17", "-ffp-contract=off", "-mfma", "-fPIC", "-shared", "-o", tmp] + HOST_SOURCES)
+            os.replace(tmp, HOST_LIBPATH)
+            with open(stamp, "w") as f:
+                f.write(_host_id())
     return HOST_LIBPATH
 
 
 def host_lib():
     global _HOST
     if _HOST is None:
+        if shutil.which("g++"):
+            build_host()                                # no-op when the digest matches
         if not os.path.exists(HOST_LIBPATH):
-            build_host()
+            raise NdpError(f"{HOST_LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
         L = ctypes.CDLL(HOST_LIBPATH)
         L.ndp_rng_replay.argtypes = [V, ctypes.c_longlong, ctypes.POINTER(DrawOp), I, I, V, ctypes.c_longlong]
         L.ndp_rng_replay.restype = I
+        L.ndp_depth_to_mesh.argtypes = [V, I, I, F, V, V, V, c_int_p, c_int_p]
+        L.ndp_erode_mesh.argtypes = [I, V, I, I, I, V]
+        L.ndp_sample_nodes.argtypes = [V, I, V, F, I, V]
+        L.ndp_edges_geodesic.argtypes = [V, I, V, V, I, V, I, I, F, I, I, V, V, V]
+        L.ndp_edges_geodesic.restype = V
+        L.ndp_geodesic_free.argtypes = [V]
+        L.ndp_geodesic_free.restype = None
+        L.ndp_node_cleanup.argtypes = [V, I, I, V]
+        L.ndp_pixel_anchors.argtypes = [V, V, V, I, I, I, F, V, V]
+        for name in ("ndp_depth_to_mesh", "ndp_erode_mesh", "ndp_sample_nodes", "ndp_node_cleanup", "ndp_pixel_anchors"):
+            getattr(L, name).restype = I
         _HOST = L
     return _HOST
 

@@ -2428,3 +2428,4 @@ extern "C" int ndp_flow_metrics(const float *flow, const float *flow_gt, const u
 }
 
 #include "ndp_nerfies.inc"
+#include "ndp_ed.inc"

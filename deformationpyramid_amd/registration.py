@@ -146,6 +146,11 @@ class Registration:
         self.tgt_pcd = tgt.to(self.device)
         self.landmarks = landmarks
 
+    def load_raw_pcds_from_depth(self, source_depth_path, tgt_depth_path, K, landmarks=None):
+        """Deformation graph + raw clouds of the embedded-deformation (N-ICP) baseline (registration.py:38-90)."""
+        from .ed import load_raw_pcds_from_depth
+        load_raw_pcds_from_depth(self, source_depth_path, tgt_depth_path, K, landmarks)
+
     def register(self, **kwargs):
         if self.deformation_model == "NDP":
             return self.optimize_deformation_pyramid(**kwargs)
@@ -157,7 +162,11 @@ class Registration:
             from .nerfies import optimize_Nerfies
             kwargs.pop("timer", None)
             return optimize_Nerfies(self, **kwargs)
-        # Sinkhorn / ED are comparison baselines outside this path
+        if self.deformation_model == "ED":                        # registration.py:112-113 -> (warped sampled cloud, valid_id)
+            from .ed import optimize_Embeded_deformation
+            kwargs.pop("timer", None)
+            return optimize_Embeded_deformation(self, **kwargs)
+        # Sinkhorn is a comparison baseline outside this path
         raise KeyError(self.deformation_model)
 
     def optimize_deformation_pyramid(self, visualize=False, timer=None):

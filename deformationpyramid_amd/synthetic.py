@@ -4,6 +4,7 @@ base clouds (no exact correspondences), target deformed by phi(q) = q + 0.05 sin
 Rz(0.3 rad), translated by (0.1, 0, -0.05); partial overlap keeps target points with x < 0.25."""
 import math
 
+import numpy as np
 import torch
 
 
@@ -64,3 +65,26 @@ def synthetic_landmarks(p, src, flow_gt, k=500, noise=0.005):
     ls = src[idx].contiguous()
     lt = (ls + flow_gt[idx] + noise * torch.randn(k, 3, generator=g)).contiguous()
     return ls, lt
+
+
+def synthetic_depth_pair(seed=0, H=120, W=160):
+    """Two small 16-bit depth maps (millimetres) of a bumpy surface, the second one deformed and shifted, for the embedded-
+    deformation (N-ICP) baseline that starts from depth images (registration.py:38-90); a hole and a depth step exercise the
+    validity and max_triangle_distance rules.  -> (depth_src, depth_tgt, K 3x3).  (tests/golden/make_golden.py carries the
+    same generator; golden F15 holds its output for seed 0.)"""
+    g = np.random.default_rng(seed)
+    v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    x, y = (u - W / 2) / W, (v - H / 2) / H
+    ph = g.uniform(0, 6.28, 4)
+    z0 = 1.0 + 0.10 * np.sin(5 * x + ph[0]) * np.cos(4 * y + ph[1]) + 0.05 * np.cos(9 * x * y + ph[2])
+    z1 = z0 + 0.03 * np.sin(6 * x + ph[3]) + 0.02 * y + 0.045     # > 0 everywhere: no pixel keeps its depth (a point that
+                                                                      # coincides with its target is upstream's sqrt(0) NaN trap)
+    out = []
+    for z in (z0, z1):
+        z = z.copy()
+        z[(x - 0.2) ** 2 + (y + 0.1) ** 2 < 0.01] = 0.0
+        z[:, : W // 8] += 0.25
+        z[:6, :] = 0.0
+        out.append(np.round(z * 1000).astype(np.uint16))
+    K = np.array([[150.0, 0, W / 2], [0, 150.0, H / 2], [0, 0, 1]], dtype=np.float32)
+    return out[0], out[1], K

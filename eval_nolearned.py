@@ -68,6 +68,35 @@ class FourDMatchPairs:
         return torch.from_numpy(src), torch.from_numpy(tgt), flow_gt, torch.from_numpy(overlap)
 
 
+class SyntheticDepthPairs:
+    """Depth-image pairs for the embedded-deformation (N-ICP) baseline, which starts from depth maps
+    (eval_nolearned.py:113-118): synthetic_depth_pair(i) written as 16-bit PNGs; the "sampled" clouds are every 9th valid
+    pixel, the ground-truth flow is the motion of the same pixel's point, overlap = valid in both frames."""
+
+    def __init__(self, n, workdir):
+        self.n, self.dir = n, workdir
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        from PIL import Image
+        from deformationpyramid_amd.geometry import depth_2_pc
+        from deformationpyramid_amd.synthetic import synthetic_depth_pair
+        d0, d1, K = synthetic_depth_pair(i)
+        paths = [os.path.join(self.dir, f"pair{i}_{k}.png") for k in "st"]
+        Image.fromarray(d0).save(paths[0])
+        Image.fromarray(d1).save(paths[1])
+        p0 = depth_2_pc(d0 / 1000.0, K).transpose(1, 2, 0)
+        p1 = depth_2_pc(d1 / 1000.0, K).transpose(1, 2, 0)
+        m0 = d0 > 0
+        src = torch.from_numpy(p0[m0]).float()[::9].contiguous()
+        tgt = torch.from_numpy(p1[d1 > 0]).float()[::9].contiguous()
+        flow_gt = torch.from_numpy((p1 - p0)[m0]).float()[::9].contiguous()
+        overlap = torch.from_numpy((d1 > 0)[m0])[::9].contiguous()
+        return src, tgt, flow_gt, overlap, paths, K
+
+
 class SyntheticPairs:
     def __init__(self, n):
         self.n = n
@@ -121,7 +150,7 @@ def main():
     world, rank, local_rank, backend = dist_setup()
     setup_seed(rank)                                                        # once per process, as upstream (seed 0 on one GPU)
     config = load_config(args.config, make_dirs=rank == 0, device=local_rank)
-    if config.deformation_model not in ("NDP", "NSFP", "Nerfies"):
+    if config.deformation_model not in ("NDP", "NSFP", "Nerfies", "ED"):
         raise KeyError(config.deformation_model)
     model = Registration(config)
     timer = Timers()
@@ -130,13 +159,34 @@ def main():
         root = os.path.join(config.data_root, benchmark)
         if os.path.isdir(root):
             data = FourDMatchPairs(config.data_root, benchmark)
+        elif config.deformation_model == "ED":
+            import tempfile
+            print(f"[{benchmark}] {root} not found: using {args.synthetic} synthetic depth pairs")
+            data = SyntheticDepthPairs(args.synthetic, tempfile.mkdtemp(prefix="ndp_depth_"))
         else:
             print(f"[{benchmark}] {root} not found: using {args.synthetic} synthetic pairs")
             data = SyntheticPairs(args.synthetic)
         lo, hi = shard_range(len(data), rank, world)                        # this rank's pairs
         items = [data[i] for i in range(lo, hi)]
         n_total = len(data)
-        if config.deformation_model in ("NSFP", "Nerfies"):                 # eval_nolearned.py:97-110
+        if config.deformation_model == "ED":                                # eval_nolearned.py:113-127 (N-ICP: needs the depth maps)
+            if len(items) and len(items[0]) < 6:
+                raise KeyError("the ED baseline needs depth images: the 4DMatch reader here does not provide them")
+            flows, kept = [], []
+            for src, tgt, flow_gt, overlap, depth_paths, cam_intrin in items:
+                model.load_pcds(src, tgt)
+                timer.tic("graph construction")
+                model.load_raw_pcds_from_depth(depth_paths[0], depth_paths[1], cam_intrin, landmarks=None)
+                timer.toc("graph construction")
+                timer.tic("registration")
+                warped, point_mask = model.register(visualize=args.visualize)
+                torch.cuda.synchronize()
+                timer.toc("registration")
+                pm = point_mask.cpu()
+                flows.append((warped - model.src_pcd[point_mask]).cpu())
+                kept.append((src, tgt, flow_gt[pm], overlap[pm]))
+            items = kept
+        elif config.deformation_model in ("NSFP", "Nerfies"):               # eval_nolearned.py:97-110
             flows = []
             for src, tgt, _, _ in items:
                 model.load_pcds(src, tgt)

@@ -120,6 +120,22 @@ int ndp_nerfies_fwd(const float *params, const float *x, int n, const float *win
 int ndp_nerfies_bwd(const float *params, const float *x, int n, float *act, const float *pe, const float *heads,
                     const float *g, float *dO_work, float *grads_part, int n_part, int p_stride, void *stream);
 
+/* ---- Embedded-deformation N-ICP baseline, SURVEY section 8 f4 --------------------------------------------------------
+ * Node graph: n_nodes positions `nodes` [n][3], axis-angle rotations `phi` [n][3], translations `t` [n][3]; every point has
+ * six anchors (`anchors` [S][6] int32, -1 = the LAST node with weight 0, as upstream's negative indexing) with skinning
+ * `weights` [S][6]; graph edges `edges` [n][K] int32 (-1 padded the same way) with `edge_w` [n][K].
+ * ndp_ed_warp: R_work [n][9] <- axis_angle_to_matrix(phi) ; y = ED_warp(x) (geometry.py:37-49).
+ * ndp_ed_arap: out[0] = arap_cost (loss.py:261-285) for the R of the last ndp_ed_warp.
+ * ndp_ed_grad: grads [phi (3n) | t (3n)] = d/d(phi, t) of <gy, ED_warp(x)> + w_arap * arap  (gy = dL/dy [S][3], e.g. the
+ * Chamfer gradient times w_cd): one workgroup per node, fixed summation order.                                          */
+int ndp_ed_warp(const float *x, int S, const int *anchors, const float *weights, const float *nodes, int n_nodes,
+                const float *phi, const float *t, float *R_work, float *y, void *stream);
+int ndp_ed_arap(const float *nodes, int n_nodes, const float *R, const float *t, const int *edges, const float *edge_w,
+                int K, float *out, void *stream);
+int ndp_ed_grad(const float *x, int S, const int *anchors, const float *weights, const float *gy, const float *nodes,
+                int n_nodes, const float *R, const float *t, const float *phi, const int *edges, const float *edge_w,
+                int K, float w_arap, float *grads, void *stream);
+
 /* Exact brute-force 1-NN in both directions (pytorch3d knn_points K=1 as called at loss.py:177-178):
  * d2x[i] = min_j |x_i - y_j|^2 (fma chain over x,y,z), idx_x[i] = lowest argmin; same for y->x.  */
 int ndp_chamfer_nn_fwd(const float *x, int S, const float *y, int T,

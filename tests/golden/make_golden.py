@@ -803,6 +803,136 @@ def F14_nerfies(nets, loss_mod, reg_mod, EasyDict, **_):
     save("F14_nerfies", **out)
 
 
+def synthetic_depth_pair(seed=0, H=120, W=160):
+    """Two small 16-bit depth maps (millimetres) of a bumpy surface, the second one deformed and shifted; a hole and a depth
+    step exercise the validity and max_triangle_distance rules.  Intrinsics for a 160x120 pinhole camera."""
+    g = np.random.default_rng(seed)
+    v, u = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+    x, y = (u - W / 2) / W, (v - H / 2) / H
+    ph = g.uniform(0, 6.28, 4)
+    z0 = 1.0 + 0.10 * np.sin(5 * x + ph[0]) * np.cos(4 * y + ph[1]) + 0.05 * np.cos(9 * x * y + ph[2])
+    z1 = z0 + 0.03 * np.sin(6 * x + ph[3]) + 0.02 * y + 0.045     # > 0 everywhere: no pixel keeps its depth (a point that
+                                                                      # coincides with its target is upstream's sqrt(0) NaN trap)
+    out = []
+    for z in (z0, z1):
+        z = z.copy()
+        z[(x - 0.2) ** 2 + (y + 0.1) ** 2 < 0.01] = 0.0                  # a hole
+        z[:, : W // 8] += 0.25                                           # a depth step: no triangles across it
+        z[:6, :] = 0.0
+        out.append(np.round(z * 1000).astype(np.uint16))
+    K = np.array([[150.0, 0, W / 2], [0, 150.0, H / 2], [0, 0, 1]], dtype=np.float32)
+    return out[0], out[1], K
+
+
+def _aa_to_matrix(aa):
+    """pytorch3d.transforms.axis_angle_to_matrix stand-in (pytorch3d is absent and un-pinned upstream): the published
+    route through the unit quaternion (axis_angle_to_quaternion, quaternion_to_matrix)."""
+    angles = torch.norm(aa, p=2, dim=-1, keepdim=True)
+    half = angles * 0.5
+    small = angles.abs() < 1e-6
+    s = torch.empty_like(angles)
+    s[~small] = torch.sin(half[~small]) / angles[~small]
+    s[small] = 0.5 - (angles[small] * angles[small]) / 48
+    q = torch.cat([torch.cos(half), aa * s], dim=-1)
+    r, i, j, k = torch.unbind(q, -1)
+    two_s = 2.0 / (q * q).sum(-1)
+    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
+                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
+                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
+    return o.reshape(q.shape[:-1] + (3, 3))
+
+
+def F15_embedded_deformation(reg_mod, loss_mod, EasyDict, **_):
+    """N-ICP baseline: the deformation graph the reference's own MVRegC build (oracle/_ref, compiled from
+    /root/reference/cxx by oracle/Makefile.ref) produces from a synthetic depth map, and optimize_Embeded_deformation end
+    to end on the synthetic depth pair with every evaluated (cd, arap) recorded."""
+    import importlib.util
+    import tempfile
+    from PIL import Image
+    so = [f for f in os.listdir(os.path.join(os.path.dirname(OUT), "..", "oracle", "_ref")) if f.startswith("MVRegC")]
+    assert so, "build oracle/_ref first: make -C oracle -f Makefile.ref"
+    spec = importlib.util.spec_from_file_location("MVRegC", os.path.join(os.path.dirname(OUT), "..", "oracle", "_ref", so[0]))
+    MVRegC = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(MVRegC)
+    import model.geometry as geo
+    geo.MVRegC = MVRegC
+    sys.modules["skimage.io"].imread = lambda path: np.array(Image.open(path))
+    tr = types.ModuleType("pytorch3d.transforms")
+    tr.axis_angle_to_matrix = _aa_to_matrix
+    sys.modules["pytorch3d.transforms"] = tr
+    sys.modules["pytorch3d"].transforms = tr
+    reg_mod.pytorch3d = sys.modules["pytorch3d"]
+    for name in ("get_deformation_graph_from_depthmap", "map_pixel_to_pcd", "depth_2_pc", "ED_warp", "pc_2_uv"):
+        setattr(reg_mod, name, getattr(geo, name))          # what `Runbaselines = True` (registration.py:9-11) would import
+    reg_mod.io.imread = sys.modules["skimage.io"].imread
+    d0, d1, K = synthetic_depth_pair(0)
+    cfg = EasyDict(dict(deformation_model="ED", device=torch.device("cpu"), iters=25, lr=0.02, max_break_count=30,
+                        break_threshold_ratio=0.01, w_ldmk=1, w_cd=1, w_arap=0.5, samples=600, max_triangle_distance=0.06,
+                        node_coverage=0.09, USE_ONLY_VALID_VERTICES=True, num_neighbors=8, ENFORCE_TOTAL_NUM_NEIGHBORS=False,
+                        SAMPLE_RANDOM_SHUFFLE=False, REMOVE_NODES_WITH_NOT_ENOUGH_NEIGHBORS=False))
+    out = {"depth_src": d0, "depth_tgt": d1, "K": K}
+    for tag, remove, cov in (("g", False, 0.09), ("gr", True, 0.05)):
+        c = EasyDict(dict(cfg, REMOVE_NODES_WITH_NOT_ENOUGH_NEIGHBORS=remove, node_coverage=cov))
+        data = geo.get_deformation_graph_from_depthmap(d0.copy(), K, c)
+        out[f"{tag}.coverage"] = np.float32(cov)
+        out[f"{tag}.graph_nodes"] = data["graph_nodes"].numpy()
+        out[f"{tag}.graph_edges"] = data["graph_edges"].numpy().astype(np.int32)
+        out[f"{tag}.graph_edges_weights"] = data["graph_edges_weights"].numpy()
+        pa, pw = data["pixel_anchors"].numpy(), data["pixel_weights"].numpy()
+        out[f"{tag}.pixel_anchors_rows"] = pa[::7, ::5].copy()
+        out[f"{tag}.pixel_weights_rows"] = pw[::7, ::5].copy()
+        out[f"{tag}.pixel_anchors_sum"] = np.int64(pa.astype(np.int64).sum())
+        out[f"{tag}.pixel_anchors_hash"] = np.int64((pa.astype(np.int64) * (1 + np.arange(pa.size).reshape(pa.shape) % 9973)).sum())
+        out[f"{tag}.pixel_weights_sum"] = np.float64(pw.astype(np.float64).sum())
+        out[f"{tag}.valid_pixels"] = np.int64((pa.sum(-1) > -4).sum())
+        print(f"  graph {tag}: {data['graph_nodes'].shape[0]} nodes, {int((pa.sum(-1) > -4).sum())} anchored pixels", flush=True)
+    vertices, faces, vpix, pim = geo.depth_to_mesh(d0.copy(), d0 > 0, K, max_triangle_distance=0.06, depth_scale=1000.)
+    out["mesh.counts"] = np.array([vertices.shape[0], faces.shape[0]])
+    out["mesh.vsum"] = vertices.astype(np.float64).sum(0)
+    out["mesh.fhash"] = np.int64((faces.astype(np.int64) * np.array([1, 3, 7])).sum())
+    out["mesh.faces_head"] = faces[:32].copy()
+    out["mesh.vpix_head"] = vpix[:32].copy()
+    # ---- the optimisation loop on the depth pair
+    with tempfile.TemporaryDirectory() as td:
+        ps, pt = os.path.join(td, "s.png"), os.path.join(td, "t.png")
+        Image.fromarray(d0).save(ps)
+        Image.fromarray(d1).save(pt)
+        trace = []
+        orig_cd, orig_arap = reg_mod.compute_truncated_chamfer_distance, reg_mod.arap_cost
+
+        def cd_hook(*a, **k):
+            v = orig_cd(*a, **k)
+            trace.append([v.item(), None])
+            return v
+
+        def arap_hook(*a, **k):
+            v = orig_arap(*a, **k)
+            trace[-1][1] = v.item()
+            return v
+
+        reg_mod.compute_truncated_chamfer_distance, reg_mod.arap_cost = cd_hook, arap_hook
+        try:
+            torch.manual_seed(11)
+            model = reg_mod.Registration(cfg)
+            pim0 = geo.depth_2_pc(d0 / 1000.0, K).transpose(1, 2, 0)
+            src_pcd = torch.from_numpy(pim0[d0 > 0]).float()[::9].contiguous()        # the "sampled" cloud of the dataset item
+            pim1 = geo.depth_2_pc(d1 / 1000.0, K).transpose(1, 2, 0)
+            tgt_pcd = torch.from_numpy(pim1[d1 > 0]).float()[::9].contiguous()
+            model.load_pcds(src_pcd, tgt_pcd)
+            model.load_raw_pcds_from_depth(ps, pt, K, landmarks=None)
+            warped, valid_id = model.register()
+        finally:
+            reg_mod.compute_truncated_chamfer_distance, reg_mod.arap_cost = orig_cd, orig_arap
+    out["e2e.src_pcd"], out["e2e.tgt_pcd"] = src_pcd.numpy(), tgt_pcd.numpy()
+    out["e2e.cd_trace"] = np.array([t[0] for t in trace], dtype=np.float64)
+    out["e2e.arap_trace"] = np.array([t[1] for t in trace], dtype=np.float64)
+    out["e2e.warped"] = warped.detach().numpy()
+    out["e2e.valid_id"] = valid_id.numpy()
+    out["e2e.seed"] = np.int64(11)
+    print(f"  loop: {len(trace)} evaluations, cd {trace[0][0]:.5f} -> {trace[-1][0]:.5f}, arap {trace[-1][1]:.3e}", flush=True)
+    save("F15_embedded_deformation", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -820,7 +950,7 @@ def main():
         "F7": F7_end_to_end, "F8": F8_metrics, "F9": F9_landmarks, "F9b": F9b_lndp_end_to_end,
         "F9c": F9c_mixed_landmark_chamfer,
         "F10": F10_benchmark, "F10b": F10b_surface_benchmark, "F11": F11_nonrigidity, "F12": F12_nsfp,
-        "F13": F13_shape_transfer, "F14": F14_nerfies,
+        "F13": F13_shape_transfer, "F14": F14_nerfies, "F15": F15_embedded_deformation,
     }
     only = [s for s in args.only.split(",") if s]
     for k, fn in todo.items():

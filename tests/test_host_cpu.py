@@ -75,12 +75,12 @@ def test_no_cpu_fallback():
     model.load_pcds(np.zeros((20, 3), np.float32), np.zeros((20, 3), np.float32))
     with pytest.raises(_native.NdpError):
         model.register()
-    for served in ("NSFP", "Nerfies"):                               # served baselines: same rule, GPU only
+    for served in ("NSFP", "Nerfies", "ED"):                         # served baselines: same rule, GPU only
         base = Registration(Config(cfg, deformation_model=served))
         base.load_pcds(np.zeros((20, 3), np.float32), np.zeros((20, 3), np.float32))
         with pytest.raises(_native.NdpError):
             base.register()
-    for other in ("Sinkhorn", "ED"):                                 # unserved comparison baselines (registration.py:123)
+    for other in ("Sinkhorn",):                                      # unserved comparison baseline (registration.py:123)
         with pytest.raises(KeyError):
             Registration(Config(cfg, deformation_model=other)).register()
 
