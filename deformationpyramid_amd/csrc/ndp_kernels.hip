@@ -96,18 +96,45 @@ struct LevelJob {
 // lane-resident slice of a 128x128 matrix in the 32x32x2 B-operand layout
 //   forward : w[ks] = W[32*wv + l31][64*h + ks]        (contraction index k = 64*h + ks)
 //   backward: w[ks] = W[64*h + ks][32*wv + l31]        (contraction index o = 64*h + ks)
-__device__ __forceinline__ void load_w_fwd(const float *W, int wv, int l31, int h, float (&w)[64]) {
-    const float4 *src = reinterpret_cast<const float4 *>(W + (32 * wv + l31) * NDP_W + 64 * h);
+// Both go through LDS: the matrix is pulled from L2/HBM by LDS-DMA as 1 KiB blocks (two consecutive rows per instruction,
+// perfectly coalesced) into the row-pair padded image the backward tiles use (float index of (r, c) = 260 (r >> 1) +
+// 128 (r & 1) + c; 64 pairs = 66 560 B, the two tile buffers of either carve), and the lanes pick their slices out of LDS.
+// (Straight from global, a lane's 64 floats are 16 float4 loads that touch 64 different cache lines per instruction --
+//  eight times the line requests the data needs: 27-28k cycles of prologue per workgroup, and per LEVEL in the final warp.)
+#define WIMG_PAIR 260
+__device__ __forceinline__ int wimg_row(int r) { return WIMG_PAIR * (r >> 1) + NDP_W * (r & 1); }
+// wave wv lays down rows 32wv .. 32wv+31 of W (16 row pairs); asynchronous, wait with s_waitcnt vmcnt(0)
+__device__ __forceinline__ void wimg_load_rows(const float *W, float *img /*LDS*/, int wv, int lane) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const float4 v = src[i];
-        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        const int q = 16 * wv + i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(W + 2 * NDP_W * q + 4 * lane),
+                                         (__attribute__((address_space(3))) void *)(img + WIMG_PAIR * q), 16, 0, 0);
     }
 }
-__device__ __forceinline__ void load_w_bwd(const float *W, int wv, int l31, int h, float (&w)[64]) {
-    const float *src = W + (64 * h) * NDP_W + 32 * wv + l31;
+// forward slice: the rows a wave reads are the rows it loaded itself, so no workgroup barrier is needed -- only its own
+// DMA (vmcnt) before the reads, and its own reads (lgkmcnt) before the image is overwritten by the next matrix.
+__device__ __forceinline__ void load_w_fwd(const float *W, float *img /*LDS*/, int wv, int l31, int h, float (&w)[64]) {
+    wimg_load_rows(W, img, wv, threadIdx.x & 63);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const float *src = img + wimg_row(32 * wv + l31) + 64 * h;
 #pragma unroll
-    for (int i = 0; i < 64; ++i) w[i] = src[i * NDP_W];
+    for (int i = 0; i < 16; ++i) {
+        const float4 v = *reinterpret_cast<const float4 *>(src + 4 * i);
+        w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+// backward (transposed) slice: a lane's column crosses the rows of all four waves -> barrier on both sides
+__device__ __forceinline__ void load_w_bwd(const float *W, float *img /*LDS*/, int wv, int l31, int h, float (&w)[64]) {
+    wimg_load_rows(W, img, wv, threadIdx.x & 63);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const float *src = img + 32 * wv + l31;
+#pragma unroll
+    for (int i = 0; i < 64; ++i) w[i] = src[wimg_row(64 * h + i)];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
 // OUT^T[o][p] += sum_k W[o][k] * in[p][k] for the 64 points of a tile: the weight slice is the MFMA A operand
@@ -204,8 +231,8 @@ __device__ __forceinline__ void fwd_load_weights(const HeadCfg &hc, const float 
     const float *W2 = P + ndp_off_Wi(&dd, 2), *b2 = P + ndp_off_bi(&dd, 2);
     const float *Wh = P + ndp_off_Wi(&dd, 3);      // == ndp_off_Wh for nonrigidity = 0
     const float *bh = Wh + hc.nh * NDP_W;
-    load_w_fwd(W1, wv, l31, h, fw.w1);
-    load_w_fwd(W2, wv, l31, h, fw.w2);
+    load_w_fwd(W1, sm + L_BUFA, wv, l31, h, fw.w1);
+    load_w_fwd(W2, sm + L_BUFA, wv, l31, h, fw.w2);
     fw.bias1 = b1[32 * wv + l31];
     fw.bias2 = b2[32 * wv + l31];
     // layer 0 (6 -> 128) also runs on the matrix pipe: K = 6 = 3 k-steps of the 32x32x2 MFMA
@@ -610,7 +637,7 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
     float *bufA = sm + LB_BUFA, *bufB = sm + LB_BUFB;
     const float *W2 = job.params + job.w_off;
     float w2t[64];
-    load_w_bwd(W2, wv, l31, h, w2t);
+    load_w_bwd(W2, sm + LB_BUFA, wv, l31, h, w2t);
     f32x16 dW2[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -722,7 +749,7 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
     const ndp_layer_desc dd = {NDP_W, 2, hc.motion, hc.rotfmt, 0, hc.mlp_scale};
     const float *W1 = job.params + ndp_off_Wi(&dd, 1);
     float w1t[64];
-    load_w_bwd(W1, wv, l31, h, w1t);
+    load_w_bwd(W1, sm + LB_BUFA, wv, l31, h, w1t);
     f32x16 dW1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m)
@@ -1780,7 +1807,8 @@ k_nsfp_dense(const float *W, const float *b, const float *hin, float *hout, int 
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
     float *bufA = sm, *bufB = sm + 64 * NDP_LD;
     float w[64];
-    load_w_fwd(W, wv, l31, h, w);
+    load_w_fwd(W, sm, wv, l31, h, w);
+    __syncthreads();                               // the weight image shares the tile buffers
     const float bias = b[32 * wv + l31];
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         load_tile_to_lds(hin + (size_t)tile * NDP_TILE * NDP_W, bufA);
