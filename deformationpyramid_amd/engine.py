@@ -10,6 +10,7 @@ Memory per slot (n_cap = t_cap = 2048, m = 9): params 1.25 MB, activations 3 MB,
 gradient partials G x 0.14 MB -- hundreds of slots fit easily in 288 GB of HBM3E.
 """
 import ctypes
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -40,7 +41,7 @@ class BatchedEngine:
         # parameter count of a gated level and level 0 uses a prefix-compatible shorter layout.
         self.lib = N.lib()
         self.desc, self.cfg, self.B = desc, cfg, B
-        self.nn_mode = nn_mode                     # None: chosen from B (see _mk_struct); 0 one-pass, 1 latency shape
+        self.nn_mode = nn_mode                     # None: chosen from B and n_cap (see _mk_struct); 0 one-pass, 1 latency shape
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise N.NdpError("BatchedEngine needs a GPU device; there is no CPU fallback")
@@ -94,7 +95,12 @@ class BatchedEngine:
         e.w_reg = c.w_reg if self.desc.nonrigidity else 0.0
         e.adam_w1, e.adam_b2, e.adam_w2, e.adam_eps = 1 - 0.9, 0.999, 1 - 0.999, 1e-8
         # few resident pairs: the one-pass kernel has only t_cap/256 workgroups per pair; the latency shape has (n_cap + t_cap)/64
-        e.nn_mode = int(self.nn_mode) if self.nn_mode is not None else (1 if self.B * (self.t_cap // 256 + 1) < 256 else 0)
+        if self.nn_mode is None and os.environ.get("NDP_NN_MODE"):            # experiments (tools/tick_bench.py): force a shape
+            self.nn_mode = int(os.environ["NDP_NN_MODE"])
+        if self.nn_mode is not None:
+            e.nn_mode = int(self.nn_mode)
+        else:
+            e.nn_mode = 1 if self.B * (self.t_cap // 256 + 1) < 256 else 0
         for name in ("geom", "state", "pts", "ldmk_t", "tgt", "params", "gpart", "adam_m", "adam_v", "act", "heads",
                      "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "dO", "nn_row"):
             setattr(e, name, getattr(self, name).data_ptr())

@@ -606,12 +606,18 @@ def test_chamfer_nn_is_exact_on_adversarial_layouts(dev, name):
 
 
 @pytest.mark.parametrize("name", ["clusters", "far_queries", "plane", "line", "lattice_ties", "single_ref", "identical",
-                                  "skewed", "large", "ragged"])
+                                  "skewed", "large", "ragged", "near_ties"])
 def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name):
     """The engine's one-pass kernels (every distance evaluated once, column minima by cross-lane butterflies, second-stage
     fold) must give the bits of the two-pass brute force: d2 and lowest index, both directions."""
     from deformationpyramid_amd import ops
-    if name == "ragged":                         # sizes that end inside a wave / a 16-target sub-chunk / a 512-target chunk
+    if name == "near_ties":                      # a shell of targets around a tight cluster of sources, radii 1e-7 apart, far from the
+        g = torch.Generator().manual_seed(5)     # origin: thousands of candidates that differ in the last bits of d2
+        d = torch.randn(1500, 3, generator=g); d = d / d.norm(dim=1, keepdim=True)
+        y = (torch.tensor([3.0, -2.0, 1.0]) + d * (0.25 + 1e-7 * torch.arange(1500)[:, None])).contiguous()
+        x = (torch.tensor([3.0, -2.0, 1.0]) + (torch.rand(900, 3, generator=g) - 0.5) * 1e-3).contiguous()
+        cases = [(x, y), (y[:1100].contiguous(), x)]
+    elif name == "ragged":                       # sizes that end inside a wave / a 16-target sub-chunk / a 512-target chunk
         g = torch.Generator().manual_seed(77)
         x, y = torch.rand(1, 3, generator=g), torch.rand(1, 3, generator=g)
         cases = [(x, y)] + [(torch.rand(s, 3, generator=g) - 0.5, torch.rand(t, 3, generator=g) - 0.5)
