@@ -15,6 +15,7 @@ Host work stays in torch (tensor plumbing, the CPU RNG replay of the reference's
 randperm calls); the optimisation itself runs in libndp_hip.so.  There is no CPU fallback:
 config.device must be a GPU.
 """
+import gc
 import queue
 import threading
 import time
@@ -61,6 +62,9 @@ class _BatchCtx:
         self.exhausted = False
 
 
+_NOT_READY = object()
+
+
 class _Lane:
     """One engine on one stream.  Pipelined control: the states of chunk k are read back while chunk k+1
     runs, so the GPU never waits for the host; a slot that finishes in chunk k is refilled before chunk k+2.
@@ -77,10 +81,15 @@ class _Lane:
         ctx, eng = self.ctx, self.eng
         jobs = []
         while self.free and not ctx.exhausted:
-            nxt = first if first is not None else ctx.next_prepared(self.stream)
+            # take what the producer has ready; wait for it only when this lane has nothing else to do -- filling all
+            # slots before the first tick kept the GPU idle for slots x 0.45 ms at the start of every batch
+            idle = not self.active and self.pending is None and not jobs
+            nxt = first if first is not None else ctx.next_prepared(self.stream, block=idle)
             first = None
             if nxt is None:
                 ctx.exhausted = True
+                break
+            if nxt is _NOT_READY:
                 break
             i, p = nxt
             slot = self.free.pop()
@@ -257,9 +266,13 @@ class Registration:
             todo = queue.Queue()
             produce()
 
-        def next_prepared(stream):
-            """Next pair off the producer queue, made visible to `stream` (a lane's stream) and to fin_stream."""
-            item = todo.get()
+        def next_prepared(stream, block=True):
+            """Next pair off the producer queue, made visible to `stream` (a lane's stream) and to fin_stream.
+            block=False: _NOT_READY when the producer has nothing queued yet."""
+            try:
+                item = todo.get(block=block)
+            except queue.Empty:
+                return _NOT_READY
             if item is None:
                 return None
             if isinstance(item, BaseException):
@@ -282,6 +295,10 @@ class Registration:
         main = torch.cuda.current_stream(dev)
         ctx = _BatchCtx(self, preps, next_prepared, fin_stream, main, chunk, m)
 
+        # the cyclic collector's full passes over thousands of live pair objects stalled every lane for 50-85 ms a few times per
+        # batch (rocprofv3 trace of the bench); nothing in the loop builds reference cycles worth collecting before it ends
+        gc_was_on = gc.isenabled()
+        gc.disable()
         try:
             first = next_prepared(main)
             B = min(slots, -(-len(pairs) // engines))
@@ -318,6 +335,9 @@ class Registration:
             torch.cuda.synchronize(dev)
             ctx.preps = ctx.next_prepared = None
             raise
+        finally:
+            if gc_was_on:
+                gc.enable()
         if th is not None:
             th.join()
         for lane in lanes:
