@@ -653,12 +653,13 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) { gWha[r] = 0.f; gWhb[r] = 0.f; }
     float4 gbh = make_float4(0.f, 0.f, 0.f, 0.f);   // partial sums of dO[.][4(t&3) ..]
+    // the input-activation tile (bufA) of tile i+1 is requested as soon as tile i is done with it, under tile i's store
+    if (job.tile0 < job.n_tiles) glds_tile(job.h_plane + (size_t)job.tile0 * NDP_TILE * NDP_W, bufA);
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
         float *plane2 = job.dz_plane + (size_t)base * NDP_W;
         PT_DECL;
         glds_tile(plane2, bufB);                                                    // h (becomes dz below), or dz
-        glds_tile(job.h_plane + (size_t)base * NDP_W, bufA);                        // h of the layer below
         if (job.from_dO) {
             const float4 dv = reinterpret_cast<const float4 *>(job.dO + (size_t)base * NDP_NHMAX)[t];
             float *dr = dOs + (t >> 2) * 17 + 4 * (t & 3);
@@ -710,6 +711,9 @@ __device__ __forceinline__ void bwd2_body(const HeadCfg &hc, const BwdJob &job, 
         PT(4);
         __syncthreads();
         PT(5);
+        // bufA (the mask of the epilogue above) is dead from here: the next tile's copy starts now, under the store
+        if (tile + job.tile_step < job.n_tiles)
+            glds_tile(job.h_plane + (size_t)(tile + job.tile_step) * NDP_TILE * NDP_W, bufA);
         store_tile_from_lds_sw(bufB, plane2);
         PT(6);
         __syncthreads();
@@ -760,12 +764,13 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
     for (int r = 0; r < 4; ++r) { gW0a[r] = 0.f; gW0b[r] = 0.f; }
     float gb1[4] = {0.f, 0.f, 0.f, 0.f};
 
+    // the h0 tile (bufA) of tile i+1 is requested as soon as tile i is done with it, under tile i's dW0 stage
+    if (job.tile0 < job.n_tiles) glds_tile(job.act + (size_t)job.tile0 * NDP_TILE * NDP_W, bufA);
     for (int tile = job.tile0; tile < job.n_tiles; tile += job.tile_step) {
         const int base = tile * NDP_TILE;
         PT_DECL;
-        // ---- dz1 tile -> bufB, h0 tile -> bufA (LDS-DMA), posenc -> pe
+        // ---- dz1 tile -> bufB (LDS-DMA), posenc -> pe
         glds_tile(job.act + (2 * (size_t)job.plane + base) * NDP_W, bufB);
-        glds_tile(job.act + (size_t)base * NDP_W, bufA);
         if (t < 64) {
             const float *hr = job.heads + (size_t)(base + t) * NDP_HROW;
             const float4 pa = *reinterpret_cast<const float4 *>(hr + 16);
@@ -793,6 +798,9 @@ __device__ __forceinline__ void bwd1_body(const HeadCfg &hc, const BwdJob &job, 
         PT(4);
         __syncthreads();
         PT(5);
+        // bufA (h0: the mask of the epilogue above) is dead from here: the next tile's h0 arrives under the dW0 stage
+        if (tile + job.tile_step < job.n_tiles)
+            glds_tile(job.act + (size_t)(tile + job.tile_step) * NDP_TILE * NDP_W, bufA);
         // ---- [dW0 | db0]^T += [pe | 1]^T dz0 on the 16x16x4 MFMA: A[c][p] = pe[c][p] (c < 6), 1 (c = 6), B[p][o] = dz0[p][o]
         {
             const float *ap = pe + (l15 < 6 ? l15 : 0) * NDP_PES;
