@@ -1289,16 +1289,37 @@ __host__ __device__ inline int nn1_lds_floats(int n_cap, bool stage_x) {
 }
 __host__ __device__ inline bool nn1_stage_x(int n_cap) { return nn1_lds_floats(n_cap, true) * 4 <= 80 * 1024; }
 
-// nearest target of source i from the row partials of the live target chunks (strict <: the first chunk keeps ties)
-__device__ __forceinline__ NnPart nn_row_fold(const NnPart *rowpart /*[chunks][n_cap]*/, int n_cap, int T, int i) {
-    if (!rowpart) return NnPart{INFINITY, -1};
-    NnPart r; r.d2 = INFINITY; r.idx = -1;
+// nearest target of NS sources (i[0..NS-1]; i < 0: skipped) from the row partials of the live target chunks (strict <: the
+// first chunk keeps ties).  The partials of up to 8 chunks x NS sources are requested together: with one load in flight per
+// thread the fold of S = 8192 x 24 chunks by the loss workgroup was a 0.2 ms latency chain.
+template <int NS>
+__device__ __forceinline__ void nn_row_fold_n(const NnPart *rowpart /*[chunks][n_cap]*/, int n_cap, int T, const int (&i)[NS],
+                                              NnPart (&r)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) { r[s].d2 = INFINITY; r[s].idx = -1; }
+    if (!rowpart) return;
     const int live = (T + NN1_YCH - 1) / NN1_YCH;
-    for (int ch = 0; ch < live; ++ch) {
-        const NnPart q = rowpart[(size_t)ch * n_cap + i];
-        if (q.d2 < r.d2) r = q;
+    for (int c0 = 0; c0 < live; c0 += 8) {
+        NnPart q[NS][8];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                q[s][k].d2 = INFINITY; q[s][k].idx = -1;
+                if (c0 + k < live && i[s] >= 0) q[s][k] = rowpart[(size_t)(c0 + k) * n_cap + i[s]];
+            }
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (q[s][k].d2 < r[s].d2) r[s] = q[s][k];
     }
-    return r;
+}
+__device__ __forceinline__ NnPart nn_row_fold(const NnPart *rowpart, int n_cap, int T, int i) {
+    const int ii[1] = {i};
+    NnPart r[1];
+    nn_row_fold_n<1>(rowpart, n_cap, T, ii, r);
+    return r[0];
 }
 
 // sources [S][3] at xs, targets [T][3] at ys; this workgroup: all sources x targets y0 .. y0 + NN1_YCH - 1.
@@ -1529,9 +1550,22 @@ k_eng_loss(ndp_engine e, int parity) {
         if (gm.K > 0) loss = sq_sum(x_out, ldmk_t, gm.K, red) * (1.0f / (float)gm.K);
         if (use_cd) {
             float sx = 0.f;
-            for (int i = t; i < gm.S; i += 256) {
-                const float v = rows_final ? e.d2x[(size_t)b * e.n_cap + i] : nn_row_fold(rowpart, e.n_cap, gm.T, i).d2;
-                sx += (v >= e.trunc) ? 0.f : sqrtf(v);
+            if (rows_final) {
+                for (int i = t; i < gm.S; i += 256) {
+                    const float v = e.d2x[(size_t)b * e.n_cap + i];
+                    sx += (v >= e.trunc) ? 0.f : sqrtf(v);
+                }
+            } else {
+                for (int i0 = t; i0 < gm.S; i0 += 2 * 256) {                 // same per-thread order as one source at a time
+                    int ii[2];
+                    NnPart r[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) ii[s] = i0 + 256 * s < gm.S ? i0 + 256 * s : -1;
+                    nn_row_fold_n<2>(rowpart, e.n_cap, gm.T, ii, r);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        if (ii[s] >= 0) sx += (r[s].d2 >= e.trunc) ? 0.f : sqrtf(r[s].d2);
+                }
             }
             sx = block_sum_256(sx, red);
             const float sy = l1_sum(d2y, gm.T, e.trunc, red);
