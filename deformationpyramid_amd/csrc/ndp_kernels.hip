@@ -1524,6 +1524,8 @@ k_eng_loss(ndp_engine e, int parity) {
     __shared__ int order[LG_CHUNK];                                       // targets grouped by their nearest source point
     __shared__ __attribute__((aligned(16))) float rows[256 * NDP_NHMAX];  // per-thread head rows
     const int b = blockIdx.y, t = threadIdx.x;
+    PT_INIT;
+    PT_DECL;
     const ndp_pair_state st = e.state[parity * e.B + b];
     ndp_pair_state *nst = e.state + (size_t)(parity ^ 1) * e.B + b;
     if (st.level >= e.m) {
@@ -1547,6 +1549,7 @@ k_eng_loss(ndp_engine e, int parity) {
 
     if (blockIdx.x == gridDim.x - 1) {                 // the extra workgroup of the pair: loss + decision, concurrently with the gradient workgroups
         float loss = 0.f;
+        PT(0);
         if (gm.K > 0) loss = sq_sum(x_out, ldmk_t, gm.K, red) * (1.0f / (float)gm.K);
         if (use_cd) {
             float sx = 0.f;
@@ -1567,8 +1570,11 @@ k_eng_loss(ndp_engine e, int parity) {
                         if (ii[s] >= 0) sx += (r[s].d2 >= e.trunc) ? 0.f : sqrtf(r[s].d2);
                 }
             }
+            PT(1);
             sx = block_sum_256(sx, red);
+            PT(2);
             const float sy = l1_sum(d2y, gm.T, e.trunc, red);
+            PT(3);
             const float lcd = sx / (float)gm.S + sy / (float)gm.T;
             loss = gm.K > 0 ? loss + e.w_cd * lcd : lcd;
         }
@@ -1621,6 +1627,8 @@ k_eng_loss(ndp_engine e, int parity) {
             // (written straight to memory: a run-time index into the private copy would push it to scratch)
             if (decision != NDP_DEC_STEP) nst->evals_per_level[st.level] = st.iter + 1;
         }
+        PT(4);
+        PT_FLUSH(48);
         return;
     }
     // ---- gradient of the loss wrt the warped points of this workgroup
@@ -1650,6 +1658,7 @@ k_eng_loss(ndp_engine e, int parity) {
             for (int a = 0; a < 3; ++a) g[a] = (w[a] - yy[a]) * inv;
         }
     }
+    PT(0);
     if (use_cd && blockIdx.x * 256 + 255 >= gm.K) {  // workgroup holds at least one sample
         // Targets whose nearest source point belongs to this workgroup, grouped per point by a counting
         // sort in LDS (O(T) per workgroup instead of a T-long scan per point), each group then sorted so
@@ -1676,6 +1685,7 @@ k_eng_loss(ndp_engine e, int parity) {
                 if (256 * (k0 + 8) >= cn) break;
             }
             __syncthreads();
+            PT(1);
             // exclusive scan of cnt -> start (Hillis-Steele over 256 entries)
             const int mine = cnt[t];
             start[t] = mine;
@@ -1691,6 +1701,7 @@ k_eng_loss(ndp_engine e, int parity) {
             __syncthreads();
             start[t] = my_start;                                          // becomes the fill cursor
             __syncthreads();
+            PT(2);
             for (int k0 = 0; k0 < LG_CHUNK / 256; k0 += 8) {
                 int li[8];
 #pragma unroll
@@ -1704,6 +1715,7 @@ k_eng_loss(ndp_engine e, int parity) {
                 if (256 * (k0 + 8) >= cn) break;
             }
             __syncthreads();
+            PT(3);
             if (live && mine > 0) {
                 int *bk = order + my_start;                               // this thread's private range
                 for (int a = 1; a < mine; ++a) {                          // insertion sort, ascending target index
@@ -1726,6 +1738,7 @@ k_eng_loss(ndp_engine e, int parity) {
         }
         if (gm.K > 0 && live) { g[0] = e.w_cd * g[0]; g[1] = e.w_cd * g[1]; g[2] = e.w_cd * g[2]; }   // registration.py:197
     }
+    PT(4);
     // ---- per-point head backward: dO = mlp_scale * dL/d(scaled head outputs); zero rows pad the last tile
     if (p < n) {
         const float *xin = e.pts + ((size_t)b * 2 + st.cur) * e.n_cap * 3 + 3 * p;
@@ -1741,6 +1754,8 @@ k_eng_loss(ndp_engine e, int parity) {
 #pragma unroll
         for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(dO_row + j) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    PT(5);
+    PT_FLUSH(36);
 }
 
 // backward of the live tiles of every pair that takes an Adam step this tick (two launches, see bwd2/bwd1)

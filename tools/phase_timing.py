@@ -52,3 +52,15 @@ for grp, lo in (("bwd2", 0), ("fwd", 12), ("bwd1", 24)):
     for i in range(lo, lo + 12):
         if buf[i]:
             print(f"   {names.get(i, i):28s} {buf[i] / tiles:9.0f}  {100.0 * buf[i] / tot:5.1f} %")
+
+lnames = {36: "loss-grad state+row fold+own term", 37: "loss-grad count pass", 38: "loss-grad scan", 39: "loss-grad fill pass",
+          40: "loss-grad sort+accumulate", 41: "loss-grad head bwd + dO",
+          48: "loss-dec state", 49: "loss-dec sx fold", 50: "loss-dec sx block sum", 51: "loss-dec sy", 52: "loss-dec decision"}
+wg_grad = B * ((eng.n_cap + 255) // 256) * ticks
+wg_dec = B * ticks
+for lo, n, tag in ((36, wg_grad, "loss gradient workgroup"), (48, wg_dec, "loss decision workgroup")):
+    tot = sum(buf[i] for i in range(lo, lo + 12))
+    print(f"{tag}: {tot / n:.0f} cycles (thread 0 wall)")
+    for i in range(lo, lo + 12):
+        if buf[i]:
+            print(f"   {lnames.get(i, i):36s} {buf[i] / n:9.0f}  {100.0 * buf[i] / tot:5.1f} %")
