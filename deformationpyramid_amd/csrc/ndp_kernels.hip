@@ -1638,6 +1638,16 @@ k_eng_loss(ndp_engine e, int parity) {
     float w[3] = {0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f};
     if (p < n) { w[0] = x_out[3 * p]; w[1] = x_out[3 * p + 1]; w[2] = x_out[3 * p + 2]; }
     const int i_self = p - gm.K;                     // sample index (negative for landmarks)
+    // Every phase below is a chain of 1-2 us global round trips (tools/phase_timing.py), so what can be requested now is: the
+    // chunk's nearest-source indices (local point of target c0 + t + 256 k, -1: not ours) travel with the row partials.
+    const bool scatter = use_cd && blockIdx.x * 256 + 255 >= gm.K;      // workgroup holds at least one sample
+    const int i_lo = (int)blockIdx.x * 256 - gm.K;                      // sample index of thread 0
+    int li[LG_CHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < LG_CHUNK / 256; ++k) {
+        const int j = t + 256 * k;
+        li[k] = scatter && j < gm.T ? idx_y[j] - i_lo : -1;
+    }
     if (p < gm.K) {
         const float invK = 1.0f / (float)gm.K;
 #pragma unroll
@@ -1659,31 +1669,28 @@ k_eng_loss(ndp_engine e, int parity) {
         }
     }
     PT(0);
-    if (use_cd && blockIdx.x * 256 + 255 >= gm.K) {  // workgroup holds at least one sample
+    if (scatter) {
         // Targets whose nearest source point belongs to this workgroup, grouped per point by a counting
         // sort in LDS (O(T) per workgroup instead of a T-long scan per point), each group then sorted so
         // that the contributions are added in ascending target index -- the order of a sequential CPU
         // scatter-add, hence bit-identical to the oracle -- without any float atomics.
         const bool live = p >= gm.K && p < n;
-        const int i_lo = (int)blockIdx.x * 256 - gm.K;                   // sample index of thread 0
         for (int c0 = 0; c0 < gm.T; c0 += LG_CHUNK) {
             const int cn = min(LG_CHUNK, gm.T - c0);
+            if (c0 > 0) {
+#pragma unroll
+                for (int k = 0; k < LG_CHUNK / 256; ++k) {
+                    const int j = t + 256 * k;
+                    li[k] = j < cn ? idx_y[c0 + j] - i_lo : -1;
+                }
+            }
             __syncthreads();
             cnt[t] = 0;
             __syncthreads();
-            // pass 1: count (targets are re-read in pass 2 rather than kept in a register array)
-            for (int k0 = 0; k0 < LG_CHUNK / 256; k0 += 8) {
-                int li[8];
+            // pass 1: count
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int j = t + 256 * (k0 + k);
-                    li[k] = j < cn ? idx_y[c0 + j] - i_lo : -1;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (li[k] >= 0 && li[k] < 256) atomicAdd(&cnt[li[k]], 1);
-                if (256 * (k0 + 8) >= cn) break;
-            }
+            for (int k = 0; k < LG_CHUNK / 256; ++k)
+                if (li[k] >= 0 && li[k] < 256) atomicAdd(&cnt[li[k]], 1);
             __syncthreads();
             PT(1);
             // exclusive scan of cnt -> start (Hillis-Steele over 256 entries)
@@ -1702,18 +1709,10 @@ k_eng_loss(ndp_engine e, int parity) {
             start[t] = my_start;                                          // becomes the fill cursor
             __syncthreads();
             PT(2);
-            for (int k0 = 0; k0 < LG_CHUNK / 256; k0 += 8) {
-                int li[8];
+            // pass 2: fill
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int j = t + 256 * (k0 + k);
-                    li[k] = j < cn ? idx_y[c0 + j] - i_lo : -1;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-                    if (li[k] >= 0 && li[k] < 256) order[atomicAdd(&start[li[k]], 1)] = c0 + t + 256 * (k0 + k);
-                if (256 * (k0 + 8) >= cn) break;
-            }
+            for (int k = 0; k < LG_CHUNK / 256; ++k)
+                if (li[k] >= 0 && li[k] < 256) order[atomicAdd(&start[li[k]], 1)] = c0 + t + 256 * k;
             __syncthreads();
             PT(3);
             if (live && mine > 0) {
@@ -1724,14 +1723,22 @@ k_eng_loss(ndp_engine e, int parity) {
                     while (q >= 0 && bk[q] > v) { bk[q + 1] = bk[q]; --q; }
                     bk[q + 1] = v;
                 }
-                for (int a = 0; a < mine; ++a) {
-                    const int j = bk[a];
-                    const float d2 = d2y[j];
-                    if (!(d2 >= e.trunc)) {
-                        const float inv = 1.0f / ((float)gm.T * sqrtf(d2));
-                        g[0] = fmaf(w[0] - tgt[3 * j], inv, g[0]);
-                        g[1] = fmaf(w[1] - tgt[3 * j + 1], inv, g[1]);
-                        g[2] = fmaf(w[2] - tgt[3 * j + 2], inv, g[2]);
+                for (int a0 = 0; a0 < mine; a0 += 4) {                    // four entries requested together, added in order
+                    float d2q[4], yq[4][3];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int j = bk[min(a0 + u, mine - 1)];
+                        d2q[u] = d2y[j];
+                        yq[u][0] = tgt[3 * j]; yq[u][1] = tgt[3 * j + 1]; yq[u][2] = tgt[3 * j + 2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        if (a0 + u < mine && !(d2q[u] >= e.trunc)) {
+                            const float inv = 1.0f / ((float)gm.T * sqrtf(d2q[u]));
+                            g[0] = fmaf(w[0] - yq[u][0], inv, g[0]);
+                            g[1] = fmaf(w[1] - yq[u][1], inv, g[1]);
+                            g[2] = fmaf(w[2] - yq[u][2], inv, g[2]);
+                        }
                     }
                 }
             }
