@@ -1,0 +1,172 @@
+// EXPERIMENT (not part of the product library): one 128 -> 128 ReLU layer over 64-point tiles, the contraction formed from
+// THREE-WAY bf16 SPLITS of both operands -- x = hi + mid + lo, every part a bf16, 24 mantissa bits in all -- as six partial
+// products (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid; the dropped ones are below 2^-24 of the product) on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation, next to the product's fp32-MFMA layer kernel (k_nsfp_dense) on the same data.
+// Question for the next round: what does an fp32-equivalent layer cost on the bf16 matrix pipe (16x the fp32 MFMA rate), and
+// how far are its results from the fp32 fma chain?   Build + run: tools/experiments/run_dense_bf16x3.py
+#include "../../deformationpyramid_amd/csrc/ndp_kernels.hip"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define XP_ROW 136                    /* bf16 per LDS row: 128 + 8 pad (272 B: b128 reads of 16 rows are conflict-free) */
+#define XP_PLANE (64 * XP_ROW)        /* bf16 per split plane */
+
+__device__ __forceinline__ void split3(float x, __bf16 &hi, __bf16 &mid, __bf16 &lo) {
+    hi = (__bf16)x;
+    const float r1 = x - (float)hi;
+    mid = (__bf16)r1;
+    const float r2 = r1 - (float)mid;
+    lo = (__bf16)r2;
+}
+
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_exp_dense_bf16x3(const float *W, const float *b, const float *hin, float *hout, int n_tiles, int layers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    __bf16 *pl = reinterpret_cast<__bf16 *>(smraw);                 // [3][64][XP_ROW]
+    float *otile = reinterpret_cast<float *>(smraw);                // [64][NDP_LD] output tile, aliases the planes
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    // weight slice: row o = 32 wv + l31, k = 16 ks + 8 h .. + 7, three bf16 parts
+    bf16x8 wA[3][8];
+    {
+        const float *wr = W + (32 * wv + l31) * NDP_W + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(wr + 16 * ks), v1 = *reinterpret_cast<const float4 *>(wr + 16 * ks + 4);
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 a, m, l;
+                split3(f[e], a, m, l);
+                wA[0][ks][e] = a; wA[1][ks][e] = m; wA[2][ks][e] = l;
+            }
+        }
+    }
+    float bias[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias[r] = b[32 * wv + mfma_row(r, h)];
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        // ---- fp32 tile -> three bf16 planes in LDS (coalesced float4 loads, split on the vector pipe)
+        const float *src = hin + (size_t)tile * NDP_TILE * NDP_W;
+        float4 v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = reinterpret_cast<const float4 *>(src)[t + 256 * i];
+        __syncthreads();                                             // the previous tile's output copy is done with LDS
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int idx = t + 256 * i, row = idx >> 5, c = 4 * (idx & 31);
+            const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            bf16x4 p0, p1, p2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                __bf16 a, m, l;
+                split3(f[e], a, m, l);
+                p0[e] = a; p1[e] = m; p2[e] = l;
+            }
+            *reinterpret_cast<bf16x4 *>(pl + row * XP_ROW + c) = p0;
+            *reinterpret_cast<bf16x4 *>(pl + XP_PLANE + row * XP_ROW + c) = p1;
+            *reinterpret_cast<bf16x4 *>(pl + 2 * XP_PLANE + row * XP_ROW + c) = p2;
+        }
+        __syncthreads();
+        for (int layer = 0; layer < layers; ++layer) {               // the same layer applied `layers` times, tile resident in LDS
+            if (layer > 0) {                                         // fp32 output tile -> registers -> planes (re-split)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int idx = t + 256 * i;
+                    v[i] = *reinterpret_cast<const float4 *>(otile + (idx >> 5) * NDP_LD + 4 * (idx & 31));
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int idx = t + 256 * i, row = idx >> 5, c = 4 * (idx & 31);
+                    const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                    bf16x4 p0, p1, p2;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        __bf16 a, m, l;
+                        split3(f[e], a, m, l);
+                        p0[e] = a; p1[e] = m; p2[e] = l;
+                    }
+                    *reinterpret_cast<bf16x4 *>(pl + row * XP_ROW + c) = p0;
+                    *reinterpret_cast<bf16x4 *>(pl + XP_PLANE + row * XP_ROW + c) = p1;
+                    *reinterpret_cast<bf16x4 *>(pl + 2 * XP_PLANE + row * XP_ROW + c) = p2;
+                }
+                __syncthreads();
+            }
+            // ---- six partial products per k-step, small terms first
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = bias[r]; acc1[r] = bias[r]; }
+            const __bf16 *r0 = pl + l31 * XP_ROW + 8 * h, *r1 = r0 + 32 * XP_ROW;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                bf16x8 B0[3], B1[3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    B0[s] = *reinterpret_cast<const bf16x8 *>(r0 + s * XP_PLANE + 16 * ks);
+                    B1[s] = *reinterpret_cast<const bf16x8 *>(r1 + s * XP_PLANE + 16 * ks);
+                }
+#define XP_MM(sw, sh)                                                                              \
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[sw][ks], B0[sh], acc0, 0, 0, 0); \
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wA[sw][ks], B1[sh], acc1, 0, 0, 0);
+                XP_MM(1, 1) XP_MM(2, 0) XP_MM(0, 2) XP_MM(1, 0) XP_MM(0, 1) XP_MM(0, 0)
+#undef XP_MM
+            }
+            __syncthreads();                                         // every wave is done reading the planes
+            epilogue_relu(acc0, acc1, otile, wv, l31, h);
+            __syncthreads();
+        }
+        store_tile_from_lds(otile, hout + (size_t)tile * NDP_TILE * NDP_W);
+    }
+}
+
+// the product's fp32-MFMA layer (k_nsfp_dense's body), `layers` times on the LDS-resident tile
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_exp_dense_f32(const float *W, const float *b, const float *hin, float *hout, int n_tiles, int layers) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *bufA = sm, *bufB = sm + 64 * NDP_LD;
+    float w[64];
+    load_w_fwd(W, sm, wv, l31, h, w);
+    __syncthreads();
+    const float bias = b[32 * wv + l31];
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        load_tile_to_lds(hin + (size_t)tile * NDP_TILE * NDP_W, bufA);
+        __syncthreads();
+        float *src = bufA, *dst = bufB;
+        for (int layer = 0; layer < layers; ++layer) {
+            f32x16 acc0, acc1;
+            acc_init_bias(bias, h, acc0, acc1);
+            tile_gemm_64x32(src, w, l31, h, acc0, acc1);
+            epilogue_relu(acc0, acc1, dst, wv, l31, h);
+            __syncthreads();
+            float *tmp = src; src = dst; dst = tmp;
+        }
+        store_tile_from_lds(src, hout + (size_t)tile * NDP_TILE * NDP_W);
+        __syncthreads();
+    }
+}
+
+// times both kernels over the same [n_tiles * 64][128] activations; ms[0] = fp32 MFMA, ms[1] = bf16 x 3
+extern "C" int exp_dense_run(const float *W, const float *b, const float *hin, float *out_f32, float *out_bf16, int n_tiles,
+                             int layers, int reps, float *ms) {
+    const int grid = n_tiles < 512 ? n_tiles : 512;
+    const int lds_x = 3 * XP_PLANE * 2 > 64 * NDP_LD * 4 ? 3 * XP_PLANE * 2 : 64 * NDP_LD * 4;
+    if (hipFuncSetAttribute((const void *)k_exp_dense_f32, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemDenseBytes) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void *)k_exp_dense_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, lds_x) != hipSuccess) return 2;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int which = 0; which < 2; ++which) {
+        for (int rep = -2; rep < reps; ++rep) {
+            if (rep == 0) (void)hipEventRecord(e0, 0);
+            if (which == 0) hipLaunchKernelGGL(k_exp_dense_f32, dim3(grid), dim3(256), kSmemDenseBytes, 0, W, b, hin, out_f32, n_tiles, layers);
+            else hipLaunchKernelGGL(k_exp_dense_bf16x3, dim3(grid), dim3(256), lds_x, 0, W, b, hin, out_bf16, n_tiles, layers);
+        }
+        (void)hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) return 3;
+        (void)hipEventElapsedTime(&ms[which], e0, e1);
+        ms[which] /= reps;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
