@@ -120,6 +120,98 @@ k_exp_dense_bf16x3(const float *W, const float *b, const float *hin, float *hout
     }
 }
 
+// ---- the shape a forward kernel with TWO resident weight matrices needs: 8 waves, 16 output columns each, 16x16x32 MFMA
+//      (a 32-column slice of both matrices in three bf16 parts is 192 registers; a 16-column slice of both is 96)
+extern "C" __global__ void __launch_bounds__(512, 1)
+k_exp_dense_bf16x3_w8(const float *Wa, const float *Wb, const float *b, const float *hin, float *hout, int n_tiles, int layers) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    __bf16 *pl = reinterpret_cast<__bf16 *>(smraw);                 // [3][64][XP_ROW]
+    float *otile = reinterpret_cast<float *>(smraw + 3 * XP_PLANE * 2);   // [64][NDP_LD] fp32 tile, separate from the planes
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l15 = lane & 15, lk = lane >> 4;
+    bf16x8 wA[2][3][4];                                              // [matrix][part][k-step of 32]
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const float *wr = (m ? Wb : Wa) + (16 * wv + l15) * NDP_W + 8 * lk;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const float4 v0 = *reinterpret_cast<const float4 *>(wr + 32 * ks), v1 = *reinterpret_cast<const float4 *>(wr + 32 * ks + 4);
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                __bf16 a, mm, l;
+                split3(f[e], a, mm, l);
+                wA[m][0][ks][e] = a; wA[m][1][ks][e] = mm; wA[m][2][ks][e] = l;
+            }
+        }
+    }
+    float bias[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bias[r] = b[16 * wv + 4 * lk + r];
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const float *src = hin + (size_t)tile * NDP_TILE * NDP_W;
+        float4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = reinterpret_cast<const float4 *>(src)[t + 512 * i];
+        __syncthreads();
+        for (int layer = 0; layer < layers; ++layer) {
+            if (layer > 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int idx = t + 512 * i;
+                    v[i] = *reinterpret_cast<const float4 *>(otile + (idx >> 5) * NDP_LD + 4 * (idx & 31));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = t + 512 * i, row = idx >> 5, c = 4 * (idx & 31);
+                const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                bf16x4 p0, p1, p2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    __bf16 a, mm, l;
+                    split3(f[e], a, mm, l);
+                    p0[e] = a; p1[e] = mm; p2[e] = l;
+                }
+                *reinterpret_cast<bf16x4 *>(pl + row * XP_ROW + c) = p0;
+                *reinterpret_cast<bf16x4 *>(pl + XP_PLANE + row * XP_ROW + c) = p1;
+                *reinterpret_cast<bf16x4 *>(pl + 2 * XP_PLANE + row * XP_ROW + c) = p2;
+            }
+            __syncthreads();
+            f32x4 acc[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g][r] = bias[r];
+            const int m = layer & 1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const __bf16 *rp = pl + (16 * g + l15) * XP_ROW + 32 * ks + 8 * lk;
+                    const bf16x8 B0 = *reinterpret_cast<const bf16x8 *>(rp);
+                    const bf16x8 B1 = *reinterpret_cast<const bf16x8 *>(rp + XP_PLANE);
+                    const bf16x8 B2 = *reinterpret_cast<const bf16x8 *>(rp + 2 * XP_PLANE);
+#define XP_M8(sw, B) acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(m ? wA[1][sw][ks] : wA[0][sw][ks], B, acc[g], 0, 0, 0);
+                    XP_M8(1, B1) XP_M8(2, B0) XP_M8(0, B2) XP_M8(1, B0) XP_M8(0, B1) XP_M8(0, B0)
+#undef XP_M8
+                }
+            }
+            // relu -> fp32 tile: lane holds point 16 g + l15, outputs 16 wv + 4 lk .. + 3
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4 *>(otile + (16 * g + l15) * NDP_LD + 16 * wv + 4 * lk) =
+                    make_float4(fmaxf(acc[g][0], 0.f), fmaxf(acc[g][1], 0.f), fmaxf(acc[g][2], 0.f), fmaxf(acc[g][3], 0.f));
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + 512 * i;
+            reinterpret_cast<float4 *>(hout + (size_t)tile * NDP_TILE * NDP_W)[idx] =
+                *reinterpret_cast<const float4 *>(otile + (idx >> 5) * NDP_LD + 4 * (idx & 31));
+        }
+    }
+}
+
 // the product's fp32-MFMA layer (k_nsfp_dense's body), `layers` times on the LDS-resident tile
 extern "C" __global__ void __launch_bounds__(256, 2)
 k_exp_dense_f32(const float *W, const float *b, const float *hin, float *hout, int n_tiles, int layers) {
@@ -148,19 +240,23 @@ k_exp_dense_f32(const float *W, const float *b, const float *hin, float *hout, i
 }
 
 // times both kernels over the same [n_tiles * 64][128] activations; ms[0] = fp32 MFMA, ms[1] = bf16 x 3
-extern "C" int exp_dense_run(const float *W, const float *b, const float *hin, float *out_f32, float *out_bf16, int n_tiles,
-                             int layers, int reps, float *ms) {
+extern "C" int exp_dense_run(const float *W, const float *b, const float *hin, float *out_f32, float *out_bf16, float *out_w8,
+                             int n_tiles, int layers, int reps, float *ms) {
     const int grid = n_tiles < 512 ? n_tiles : 512;
     const int lds_x = 3 * XP_PLANE * 2 > 64 * NDP_LD * 4 ? 3 * XP_PLANE * 2 : 64 * NDP_LD * 4;
     if (hipFuncSetAttribute((const void *)k_exp_dense_f32, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemDenseBytes) != hipSuccess) return 1;
     if (hipFuncSetAttribute((const void *)k_exp_dense_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, lds_x) != hipSuccess) return 2;
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    for (int which = 0; which < 2; ++which) {
+    const int lds_w8 = 3 * XP_PLANE * 2 + 64 * NDP_LD * 4;
+    if (hipFuncSetAttribute((const void *)k_exp_dense_bf16x3_w8, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w8) != hipSuccess) return 5;
+    const int grid8 = n_tiles < 256 ? n_tiles : 256;
+    for (int which = 0; which < 3; ++which) {
         for (int rep = -2; rep < reps; ++rep) {
             if (rep == 0) (void)hipEventRecord(e0, 0);
             if (which == 0) hipLaunchKernelGGL(k_exp_dense_f32, dim3(grid), dim3(256), kSmemDenseBytes, 0, W, b, hin, out_f32, n_tiles, layers);
-            else hipLaunchKernelGGL(k_exp_dense_bf16x3, dim3(grid), dim3(256), lds_x, 0, W, b, hin, out_bf16, n_tiles, layers);
+            else if (which == 1) hipLaunchKernelGGL(k_exp_dense_bf16x3, dim3(grid), dim3(256), lds_x, 0, W, b, hin, out_bf16, n_tiles, layers);
+            else hipLaunchKernelGGL(k_exp_dense_bf16x3_w8, dim3(grid8), dim3(512), lds_w8, 0, W, W, b, hin, out_w8, n_tiles, layers);
         }
         (void)hipEventRecord(e1, 0);
         if (hipEventSynchronize(e1) != hipSuccess) return 3;

@@ -26,10 +26,10 @@ for tag, scale_h, scale_w in (("activations ~U[0,1), Xavier-size weights", 1.0, 
     b = ((torch.rand(128, generator=g) - 0.5) * 0.1 * scale_h).to(dev)
     print(f"{tag}: n = {n} points")
     for layers in (1, 2, 4):
-        y32 = torch.empty(n, 128, device=dev); y16 = torch.empty(n, 128, device=dev)
-        ms = (ctypes.c_float * 2)()
+        y32 = torch.empty(n, 128, device=dev); y16 = torch.empty(n, 128, device=dev); y8 = torch.empty(n, 128, device=dev)
+        ms = (ctypes.c_float * 3)()
         p = lambda t: ctypes.c_void_p(t.data_ptr())
-        rc = L.exp_dense_run(p(W), p(b), p(h), p(y32), p(y16), n_tiles, layers, reps, ms)
+        rc = L.exp_dense_run(p(W), p(b), p(h), p(y32), p(y16), p(y8), n_tiles, layers, reps, ms)
         torch.cuda.synchronize()
         assert rc == 0, rc
         ref = h[:65536].double()
@@ -38,6 +38,7 @@ for tag, scale_h, scale_w in (("activations ~U[0,1), Xavier-size weights", 1.0, 
         s = ref.abs().max().item()
         e32 = (y32[:65536].double() - ref).abs().max().item() / s
         e16 = (y16[:65536].double() - ref).abs().max().item() / s
+        e8 = (y8[:65536].double() - ref).abs().max().item() / s
         flop = 2.0 * n * 128 * 128 * layers
         print(f"  {layers} layer(s): fp32 MFMA {ms[0]:.4f} ms {flop / ms[0] / 1e9:6.1f} TFLOP/s err {e32:.2e} | bf16 x 3 {ms[1]:.4f} ms "
-              f"{flop / ms[1] / 1e9:6.1f} TFLOP/s err {e16:.2e} | ratio {ms[0] / ms[1]:.2f}")
+              f"{flop / ms[1] / 1e9:6.1f} TFLOP/s err {e16:.2e} | ratio {ms[0] / ms[1]:.2f} | 8 waves x 16 cols {ms[2]:.4f} ms err {e8:.2e} ratio {ms[0] / ms[2]:.2f}")
