@@ -239,6 +239,131 @@ k_exp_dense_f32(const float *W, const float *b, const float *hin, float *hout, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient dW[o][k] += sum_p dz[p][o] h[p][k] (contraction over the tile's 64 points): both MFMA operands need eight
+// consecutive POINTS of one feature per lane -- the transpose of the row-major [point][feature] planes the other contractions
+// read.  ds_read_b64_tr_b16 does that transposition on the way out of LDS: every lane supplies the address of 8 bytes M[lane];
+// within a 16-lane group lane l receives M[4 j + (l >> 2)][l & 3], j = 0..3 (measured: tools/experiments/probe_ds_read_tr.hip).
+// With lane 4 j + q of a group pointing at row p0 + j, columns c0 + 4 q .. + 3, lane l ends up with column c0 + (l & 15) of rows
+// p0 .. p0 + 3 -- any row stride works, so ONE set of row-major planes serves every contraction of the backward.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16 *plane, int ks, int f0, int lane) {
+    const int lam = lane & 15, g = (lane >> 4) & 1, p0 = 16 * ks + 8 * (lane >> 5);
+    const __bf16 *a = plane + (p0 + (lam >> 2)) * XP_ROW + f0 + 16 * g + 4 * (lam & 3);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)(a + 4 * XP_ROW));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ void split_tile_to_planes(const float *src /*global [64][128]*/, __bf16 *pl /*[3][64][XP_ROW]*/, int t) {
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = reinterpret_cast<const float4 *>(src)[t + 512 * i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = t + 512 * i, row = idx >> 5, c = 4 * (idx & 31);
+        const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        bf16x4 p0, p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            __bf16 a, mm, l;
+            split3(f[e], a, mm, l);
+            p0[e] = a; p1[e] = mm; p2[e] = l;
+        }
+        *reinterpret_cast<bf16x4 *>(pl + row * XP_ROW + c) = p0;
+        *reinterpret_cast<bf16x4 *>(pl + XP_PLANE + row * XP_ROW + c) = p1;
+        *reinterpret_cast<bf16x4 *>(pl + 2 * XP_PLANE + row * XP_ROW + c) = p2;
+    }
+}
+
+// 8 waves: wave w owns the 32 x 32 blocks (o-block w & 3, k-blocks 2 (w >> 2), 2 (w >> 2) + 1) of dW
+extern "C" __global__ void __launch_bounds__(512, 1)
+k_exp_wgrad_bf16x3(const float *dz, const float *hin, float *gpart /*[grid][128][128]*/, int n_tiles, int rep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smraw[];
+    __bf16 *pz = reinterpret_cast<__bf16 *>(smraw), *ph = pz + 3 * XP_PLANE;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    const int ob = wv & 3, kb = 2 * (wv >> 2);
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        __syncthreads();
+        split_tile_to_planes(dz + (size_t)tile * NDP_TILE * NDP_W, pz, t);
+        split_tile_to_planes(hin + (size_t)tile * NDP_TILE * NDP_W, ph, t);
+        __syncthreads();
+        for (int q = 0; q < rep; ++q)                                // the contraction repeated `rep` times on the resident tile
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 A[3], B[2][3];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                A[s] = tr_frag(pz + s * XP_PLANE, ks, 32 * ob, lane);
+                B[0][s] = tr_frag(ph + s * XP_PLANE, ks, 32 * kb, lane);
+                B[1][s] = tr_frag(ph + s * XP_PLANE, ks, 32 * kb + 32, lane);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+#define XP_MW(sa, sb) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[sa], B[m][sb], acc[m], 0, 0, 0);
+                XP_MW(1, 1) XP_MW(2, 0) XP_MW(0, 2) XP_MW(1, 0) XP_MW(0, 1) XP_MW(0, 0)
+#undef XP_MW
+            }
+        }
+    }
+    float *G = gpart + (size_t)blockIdx.x * NDP_W * NDP_W;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) G[(32 * ob + mfma_row(r, h)) * NDP_W + 32 * (kb + m) + l31] = acc[m][r];
+}
+
+// the product's fp32 outer product (tile images by LDS-DMA, tile_outer_128x32_sw), same partial layout
+extern "C" __global__ void __launch_bounds__(256, 2)
+k_exp_wgrad_f32(const float *dz, const float *hin, float *gpart, int n_tiles, int rep) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, l31 = lane & 31, h = lane >> 5;
+    float *bufA = sm + LB_BUFA, *bufB = sm + LB_BUFB;
+    f32x16 dW[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dW[m][r] = 0.f;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        glds_tile(dz + (size_t)tile * NDP_TILE * NDP_W, bufB);
+        glds_tile(hin + (size_t)tile * NDP_TILE * NDP_W, bufA);
+        glds_wait();
+        __syncthreads();
+        for (int q = 0; q < rep; ++q) tile_outer_128x32_sw<false>(bufB, bufA, wv, l31, h, dW, cs);
+        __syncthreads();
+    }
+    store_dW(gpart + (size_t)blockIdx.x * NDP_W * NDP_W, dW, wv, l31, h);
+}
+
+extern "C" int exp_wgrad_run(const float *dz, const float *hin, float *g_f32, float *g_bf16, int n_tiles, int rep, int reps, float *ms) {
+    const int lds_w = 2 * 3 * XP_PLANE * 2;
+    if (hipFuncSetAttribute((const void *)k_exp_wgrad_f32, hipFuncAttributeMaxDynamicSharedMemorySize, kSmemBwdBytes) != hipSuccess) return 1;
+    if (hipFuncSetAttribute((const void *)k_exp_wgrad_bf16x3, hipFuncAttributeMaxDynamicSharedMemorySize, lds_w) != hipSuccess) return 2;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    for (int which = 0; which < 2; ++which) {
+        for (int it = -2; it < reps; ++it) {
+            if (it == 0) (void)hipEventRecord(e0, 0);
+            if (which == 0) hipLaunchKernelGGL(k_exp_wgrad_f32, dim3(512), dim3(256), kSmemBwdBytes, 0, dz, hin, g_f32, n_tiles, rep);
+            else hipLaunchKernelGGL(k_exp_wgrad_bf16x3, dim3(256), dim3(512), lds_w, 0, dz, hin, g_bf16, n_tiles, rep);
+        }
+        (void)hipEventRecord(e1, 0);
+        if (hipEventSynchronize(e1) != hipSuccess) return 3;
+        (void)hipEventElapsedTime(&ms[which], e0, e1);
+        ms[which] /= reps;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return hipGetLastError() == hipSuccess ? 0 : 4;
+}
+
 // times both kernels over the same [n_tiles * 64][128] activations; ms[0] = fp32 MFMA, ms[1] = bf16 x 3
 extern "C" int exp_dense_run(const float *W, const float *b, const float *hin, float *out_f32, float *out_bf16, float *out_w8,
                              int n_tiles, int layers, int reps, float *ms) {

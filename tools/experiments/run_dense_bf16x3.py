@@ -42,3 +42,21 @@ for tag, scale_h, scale_w in (("activations ~U[0,1), Xavier-size weights", 1.0, 
         flop = 2.0 * n * 128 * 128 * layers
         print(f"  {layers} layer(s): fp32 MFMA {ms[0]:.4f} ms {flop / ms[0] / 1e9:6.1f} TFLOP/s err {e32:.2e} | bf16 x 3 {ms[1]:.4f} ms "
               f"{flop / ms[1] / 1e9:6.1f} TFLOP/s err {e16:.2e} | ratio {ms[0] / ms[1]:.2f} | 8 waves x 16 cols {ms[2]:.4f} ms err {e8:.2e} ratio {ms[0] / ms[2]:.2f}")
+
+# ---- weight gradient: dW = dz^T h over all tiles (per-workgroup partials summed here)
+dz = ((torch.rand(n, 128, generator=g) - 0.5) * 2e-4).to(dev)
+h = torch.rand(n, 128, generator=g).to(dev)
+h = torch.where(torch.rand(n, 128, generator=g).to(dev) < 0.5, torch.zeros_like(h), h)        # post-ReLU sparsity
+g32 = torch.zeros(512, 128, 128, device=dev); g16 = torch.zeros(256, 128, 128, device=dev)
+ref = dz.double().T @ h.double()
+s = ref.abs().max().item()
+flop = 2.0 * n * 128 * 128
+for rep in (1, 2, 4):
+    ms = (ctypes.c_float * 2)()
+    rc = L.exp_wgrad_run(p(dz), p(h), p(g32), p(g16), n_tiles, rep, reps, ms)
+    torch.cuda.synchronize()
+    assert rc == 0, rc
+    e32 = (g32.double().sum(0) / rep - ref).abs().max().item() / s
+    e16 = (g16.double().sum(0) / rep - ref).abs().max().item() / s
+    print(f"weight gradient dz^T h x {rep} on the resident tile, n = {n}: fp32 MFMA outer product {ms[0]:.4f} ms {rep * flop / ms[0] / 1e9:6.1f} TFLOP/s "
+          f"err {e32:.2e} | bf16 x 3 with transposing LDS reads {ms[1]:.4f} ms {rep * flop / ms[1] / 1e9:6.1f} TFLOP/s err {e16:.2e} | ratio {ms[0] / ms[1]:.2f}")
