@@ -390,6 +390,15 @@ class Registration:
         sampling permutations into ONE pinned buffer, one asynchronous upload, one launch for the two cloud means.
         Centring, sampling and the slot fill itself happen on the device (k_eng_load)."""
         c = self.config
+        # (upstream fails deep inside knn_points / mean() on such inputs; say what is wrong instead)
+        for name, cloud in (("source", src_pcd), ("target", tgt_pcd)):
+            if not torch.is_tensor(cloud) or cloud.ndim != 2 or cloud.shape[1] != 3 or cloud.shape[0] < 1:
+                raise ValueError(f"{name} cloud must be a [N, 3] tensor with N >= 1, got "
+                                 f"{tuple(cloud.shape) if torch.is_tensor(cloud) else type(cloud).__name__}")
+        if landmarks is not None:
+            ls, lt = landmarks
+            if ls.ndim != 2 or ls.shape[1] != 3 or tuple(ls.shape) != tuple(lt.shape) or ls.shape[0] < 1:
+                raise ValueError(f"landmarks must be two [K, 3] tensors with the same K >= 1, got {tuple(ls.shape)} and {tuple(lt.shape)}")
         dev = self._dev()
         if c.depth != 3 or c.width != 128:
             raise N.NdpError("the HIP kernels are specialised for depth=3, width=128 (NDP.yaml / LNDP.yaml)")

@@ -85,6 +85,26 @@ def test_no_cpu_fallback():
             Registration(Config(cfg, deformation_model=other)).register()
 
 
+def test_register_rejects_malformed_clouds_before_touching_the_device():
+    """Empty / wrongly shaped clouds and mismatched landmark sets are reported as such (upstream dies inside knn_points)."""
+    from deformationpyramid_amd.config import Config
+    from deformationpyramid_amd.registration import Registration
+    cfg = Config(deformation_model="NDP", device=torch.device("cpu"), depth=3, width=128, k0=-8, m=2, w_reg=0.0,
+                 rotation_format="axis_angle", motion_type="SE3", samples=10, iters=5, lr=0.01, max_break_count=15,
+                 break_threshold_ratio=0.001, w_ldmk=1.0, w_cd=0.0)
+    ok = np.zeros((20, 3), np.float32)
+    for src, tgt in ((np.zeros((0, 3), np.float32), ok), (ok, np.zeros((0, 3), np.float32)), (np.zeros((20, 2), np.float32), ok),
+                     (np.zeros((20,), np.float32), ok)):
+        model = Registration(cfg)
+        model.load_pcds(src, tgt)
+        with pytest.raises(ValueError, match="cloud must be"):
+            model.register()
+    model = Registration(cfg)
+    model.load_pcds(ok, ok, landmarks=(torch.zeros(5, 3), torch.zeros(4, 3)))
+    with pytest.raises(ValueError, match="landmarks"):
+        model.register()
+
+
 def test_config_files_and_join_constructor():
     from deformationpyramid_amd.config import load_config
     c = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=torch.device("cpu"))
