@@ -1207,6 +1207,8 @@ k_eng_fwd(ndp_engine e, int parity) {
     PT_FLUSH(12);
 }
 
+#include "ndp_fwd_bf16.inc"
+
 // ------------------------------------------------------------------------------------------------
 // One-pass exact 1-NN for the engine: every squared distance d2(x_i, y_j) is evaluated ONCE and serves both
 // directions (loss.py:177-178 calls knn_points twice; SURVEY 8(d) counts 8 S T FLOP for one pass).
@@ -2395,6 +2397,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (nn && e->nn_mode != 0 && e->nn_mode != 1) return fail(NDP_E_INVALID, "ndp_engine_run: nn_mode must be 0 (one pass) or 1 (latency shape)");
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
+    const dim3 g_fwd8(e->G > 1 ? e->G / 2 : 1, e->B);              // one 8-wave workgroup per CU: half as many, twice the tiles each
+    if (e->fwd_mode != 0 && e->fwd_mode != 1) return fail(NDP_E_INVALID, "ndp_engine_run: fwd_mode must be 0 (fp32 MFMA) or 1 (bf16 splits)");
+    if (e->fwd_mode == 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     const dim3 g_nn(nn1_row_chunks(e->t_cap), e->B);
     const dim3 g_nn_lat(e->n_cap / 64 + e->t_cap / 64, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
@@ -2404,7 +2409,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         hipEvent_t *q = ev ? ev + (size_t)k * (NDP_TICK_KERNELS + 1) : nullptr;
         int j = 0;
 #define NDP_EV() do { if (q) (void)hipEventRecord(q[j++], s); } while (0)
-        NDP_EV(); hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
+        NDP_EV();
+        if (e->fwd_mode == 1) hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity);
+        else hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         NDP_EV();
         if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);
         else if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, nn_lds, s, *e, parity, stage_x);

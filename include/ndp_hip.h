@@ -229,7 +229,10 @@ typedef struct ndp_engine {
     const float *adam_tab;           /* [iters+1][2]: {neg_step, bc2_sqrt} for t = 1..iters     */
     float *dO;                       /* [B][n_cap][16] mlp_scale * dL/d(head outputs), this tick */
     float *nn_row;                   /* one-pass 1-NN row partials, B x ndp_engine_nn_workspace() floats (NULL if w_cd == 0) */
-    int nn_mode, pad_i;              /* 0: one-pass kernel (throughput, many pairs resident); 1: latency shape -- two passes in
+    int nn_mode, fwd_mode;           /* fwd_mode 0: level forward on the fp32 MFMA, bitwise the oracle's fma chain (default);
+                                        1 (opt-in): its two 128 x 128 layers from three-way bf16 splits on the bf16 MFMA --
+                                        fp32-level accuracy, not bitwise the chain (csrc/ndp_fwd_bf16.inc).
+                                        nn_mode 0: one-pass kernel (throughput, many pairs resident); 1: latency shape -- two passes in
                                         64-query workgroups, S/64 + T/64 of them per pair -- for a handful of resident pairs   */
 } ndp_engine;
 
