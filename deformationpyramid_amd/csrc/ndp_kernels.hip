@@ -2410,7 +2410,10 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         int j = 0;
 #define NDP_EV() do { if (q) (void)hipEventRecord(q[j++], s); } while (0)
         NDP_EV();
-        if (e->fwd_mode == 1) hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity);
+        if (e->fwd_mode == 1) {
+            hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity);
+            hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
+        }
         else hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         NDP_EV();
         if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);

@@ -51,7 +51,7 @@ for grp, lo in (("bwd2", 0), ("fwd", 12), ("bwd1", 24)):
     print(f"{grp}: {tot / tiles:.0f} cycles per tile (thread 0 wall)")
     for i in range(lo, lo + 12):
         if buf[i]:
-            print(f"   {names.get(i, i):28s} {buf[i] / tiles:9.0f}  {100.0 * buf[i] / tot:5.1f} %")
+            print(f"   {str(names.get(i, i)):28s} {buf[i] / tiles:9.0f}  {100.0 * buf[i] / tot:5.1f} %")
 
 lnames = {36: "loss-grad state+row fold+own term", 37: "loss-grad count pass", 38: "loss-grad scan", 39: "loss-grad fill pass",
           40: "loss-grad sort+accumulate", 41: "loss-grad head bwd + dO",
@@ -64,3 +64,11 @@ for lo, n, tag in ((36, wg_grad, "loss gradient workgroup"), (48, wg_dec, "loss 
     for i in range(lo, lo + 12):
         if buf[i]:
             print(f"   {lnames.get(i, i):36s} {buf[i] / n:9.0f}  {100.0 * buf[i] / tot:5.1f} %")
+
+if os.environ.get("NDP_FWD_MODE") == "1":
+    f8 = ["-", "layer 0 (VALU) + split + planes + h0 store", "barrier", "-", "layer 1 MFMA + epilogue", "barrier", "-",
+          "layer 2 MFMA + epilogue", "barrier", "heads (waves 0..3)", "-"]
+    tot = sum(buf[12 + i] for i in range(11))
+    print(f"fwd8 (bf16 splits): {tot / tiles:.0f} cycles per tile (thread 0 wall)")
+    for i, nm in enumerate(f8):
+        print(f"   {nm:40s} {buf[12 + i] / tiles:9.0f}  {100.0 * buf[12 + i] / max(tot, 1):5.1f} %")
