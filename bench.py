@@ -223,9 +223,9 @@ def main():
                          "D Sim3/euler, 6000 samples of 24 856-pt clouds (shape transfer); E LNDP.yaml, 500 landmarks, m = 10")
     ap.add_argument("--fixed-work", action="store_true",
                     help="SURVEY 8(d) config B: early stop off, 50 iterations x 9 levels = 450 Adam steps per pair")
-    ap.add_argument("--fwd-mode", type=int, default=0, choices=[0, 1],
-                    help="0 (default): level forward on the fp32 MFMA, bitwise the oracle's fma chain; 1: OPT-IN forward whose 128x128 "
-                         "layers are three-way bf16 splits on the bf16 MFMA (fp32-level accuracy, not bitwise; csrc/ndp_fwd_bf16.inc)")
+    ap.add_argument("--gemm-mode", type=int, default=0, choices=list(range(8)),
+                    help="0 (default): level kernels on the fp32 MFMA, bitwise the oracle's fma chain; OPT-IN mask 1 forward | 2 bwd1 | 4 bwd2: "
+                         "their 128x128 contractions as three-way bf16 splits on the bf16 MFMA (fp32-level accuracy, not bitwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 register() latency measurement")
@@ -299,7 +299,7 @@ def main():
         else:
             pairs.append((src.to(dev), tgt.to(dev)))
         gts.append((flow_gt, overlap))
-    os.environ["NDP_FWD_MODE"] = str(args.fwd_mode)          # read by every engine this process creates
+    os.environ["NDP_GEMM_MODE"] = str(args.gemm_mode)          # read by every engine this process creates
     model = Registration(cfg)
     torch.manual_seed(rank)
 
@@ -355,8 +355,9 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "survey_8d_config": args.config,
-                   "forward_arithmetic": ("fp32 MFMA, bitwise the fma chain" if args.fwd_mode == 0 else
-                                          "OPT-IN: 128x128 layers as three-way bf16 splits on the bf16 MFMA, fp32 accumulate"),
+                   "contraction_arithmetic": ("fp32 MFMA, bitwise the fma chain" if args.gemm_mode == 0 else
+                                              f"OPT-IN mask {args.gemm_mode} (1 fwd | 2 bwd1 | 4 bwd2): 128x128 contractions as three-way bf16 "
+                                              "splits on the bf16 MFMA, fp32 accumulate"),
                    "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B * args.engines, "engines_per_gpu": args.engines, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective",
                    "backend": ("none" if not use_dist else ("rccl" if backend == "nccl" else backend)),
                    "seeds": "rank r registers synthetic_pair(r*pairs_per_step + i), i < pairs_per_step; torch.manual_seed(r) "

@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libndp_hip.so")
 SOURCES = ["ndp_kernels.hip"]
-HEADERS = ["ndp_device.h", "ndp_nerfies.inc", "ndp_ed.inc", "ndp_fwd_bf16.inc", os.path.join("..", "..", "include", "ndp_hip.h"), os.path.join("..", "..", "include", "ndp_types.h")]
+HEADERS = ["ndp_device.h", "ndp_nerfies.inc", "ndp_ed.inc", "ndp_fwd_bf16.inc", "ndp_bwd_bf16.inc", os.path.join("..", "..", "include", "ndp_hip.h"), os.path.join("..", "..", "include", "ndp_types.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 NDP_MAX_LEVELS = 16
@@ -58,7 +58,7 @@ class Engine(ctypes.Structure):
                 ("act", ctypes.c_void_p), ("heads", ctypes.c_void_p),
                 ("d2x", ctypes.c_void_p), ("idx_x", ctypes.c_void_p), ("d2y", ctypes.c_void_p),
                 ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p), ("dO", ctypes.c_void_p),
-                ("nn_row", ctypes.c_void_p), ("nn_mode", ctypes.c_int), ("fwd_mode", ctypes.c_int)]
+                ("nn_row", ctypes.c_void_p), ("nn_mode", ctypes.c_int), ("gemm_mode", ctypes.c_int)]
 
 
 class WarpJob(ctypes.Structure):

@@ -1814,6 +1814,8 @@ k_eng_bwd1(ndp_engine e, int parity) {
     PT_FLUSH(24);
 }
 
+#include "ndp_bwd_bf16.inc"
+
 // fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state)
 extern "C" __global__ void __launch_bounds__(256)
 k_eng_update(ndp_engine e, int parity) {
@@ -2398,8 +2400,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
     const dim3 g_fwd8(e->G > 1 ? e->G / 2 : 1, e->B);              // one 8-wave workgroup per CU: half as many, twice the tiles each
-    if (e->fwd_mode != 0 && e->fwd_mode != 1) return fail(NDP_E_INVALID, "ndp_engine_run: fwd_mode must be 0 (fp32 MFMA) or 1 (bf16 splits)");
-    if (e->fwd_mode == 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
+    if (e->gemm_mode < 0 || e->gemm_mode > 7) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on bf16 splits");
+    if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
+    if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd8Bytes)) return rc;
     const dim3 g_nn(nn1_row_chunks(e->t_cap), e->B);
     const dim3 g_nn_lat(e->n_cap / 64 + e->t_cap / 64, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
@@ -2410,7 +2413,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         int j = 0;
 #define NDP_EV() do { if (q) (void)hipEventRecord(q[j++], s); } while (0)
         NDP_EV();
-        if (e->fwd_mode == 1) {
+        if (e->gemm_mode & 1) {
             hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity);
             hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
         }
@@ -2420,7 +2423,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         else if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, nn_lds, s, *e, parity, stage_x);
         NDP_EV(); hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         NDP_EV(); hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
-        NDP_EV(); hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
+        NDP_EV();
+        if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd8Bytes, s, *e, parity);
+        else hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV(); hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
         NDP_EV();
 #undef NDP_EV

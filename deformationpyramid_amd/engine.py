@@ -36,13 +36,13 @@ class OptConfig:
 
 
 class BatchedEngine:
-    def __init__(self, desc: LayerDesc, cfg: OptConfig, B: int, n_cap: int, t_cap: int, device, G=None, nn_mode=None, fwd_mode=None):
+    def __init__(self, desc: LayerDesc, cfg: OptConfig, B: int, n_cap: int, t_cap: int, device, G=None, nn_mode=None, gemm_mode=None):
         # desc.nonrigidity = True means "every level but the first carries the gate" (nets.py:26); P is then the
         # parameter count of a gated level and level 0 uses a prefix-compatible shorter layout.
         self.lib = N.lib()
         self.desc, self.cfg, self.B = desc, cfg, B
         # 0: level forward on the fp32 MFMA (bitwise the oracle's chain, default); 1: opt-in, bf16-split layers (csrc/ndp_fwd_bf16.inc)
-        self.fwd_mode = int(fwd_mode) if fwd_mode is not None else int(os.environ.get("NDP_FWD_MODE", "0"))
+        self.gemm_mode = int(gemm_mode) if gemm_mode is not None else int(os.environ.get("NDP_GEMM_MODE", "0"))
         self.nn_mode = nn_mode                     # None: chosen from B and n_cap (see _mk_struct); 0 one-pass, 1 latency shape
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -92,7 +92,7 @@ class BatchedEngine:
         e.m, e.k0, e.P, e.p_stride = c.m, c.k0, self.P, self.p_stride
         e.iters, e.max_break_count, e.early_stop = c.iters, c.max_break_count, int(bool(c.early_stop))
         e.B, e.G, e.n_cap, e.t_cap = self.B, self.G, self.n_cap, self.t_cap
-        e.fwd_mode = self.fwd_mode
+        e.gemm_mode = self.gemm_mode
         e.break_threshold_ratio = c.break_threshold_ratio
         e.w_cd, e.trunc = c.w_cd, c.trunc
         e.w_reg = c.w_reg if self.desc.nonrigidity else 0.0

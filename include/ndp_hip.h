@@ -229,9 +229,9 @@ typedef struct ndp_engine {
     const float *adam_tab;           /* [iters+1][2]: {neg_step, bc2_sqrt} for t = 1..iters     */
     float *dO;                       /* [B][n_cap][16] mlp_scale * dL/d(head outputs), this tick */
     float *nn_row;                   /* one-pass 1-NN row partials, B x ndp_engine_nn_workspace() floats (NULL if w_cd == 0) */
-    int nn_mode, fwd_mode;           /* fwd_mode 0: level forward on the fp32 MFMA, bitwise the oracle's fma chain (default);
-                                        1 (opt-in): its two 128 x 128 layers from three-way bf16 splits on the bf16 MFMA --
-                                        fp32-level accuracy, not bitwise the chain (csrc/ndp_fwd_bf16.inc).
+    int nn_mode, gemm_mode;          /* gemm_mode 0 (default): level kernels on the fp32 MFMA, bitwise the oracle's fma chain.  OPT-IN
+                                        mask: 1 forward, 2 bwd1, 4 bwd2 with their 128 x 128 contractions as three-way bf16 splits
+                                        on the bf16 MFMA -- fp32-level accuracy, not bitwise the chain (csrc/ndp_*_bf16.inc).
                                         nn_mode 0: one-pass kernel (throughput, many pairs resident); 1: latency shape -- two passes in
                                         64-query workgroups, S/64 + T/64 of them per pair -- for a handful of resident pairs   */
 } ndp_engine;

@@ -195,7 +195,7 @@ def test_landmark_and_adam_bit_exact(dev):
 
 
 # ----------------------------------------------------------------------------- batched engine
-def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3, seed=7, G=None, ratio=0.001, nn_mode=None, fwd_mode=None):
+def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3, seed=7, G=None, ratio=0.001, nn_mode=None, gemm_mode=None):
     from deformationpyramid_amd.engine import BatchedEngine, OptConfig
     kw = VARIANTS[tag]
     cfg = OptConfig(m=m, iters=iters, early_stop=early_stop, w_cd=w_cd, trunc=trunc, break_threshold_ratio=ratio)
@@ -205,7 +205,7 @@ def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3,
         pyr = seeded_pyramid(seed + b, m=m, **kw)
         d = pyr.descs[0]
         if eng is None:
-            eng = BatchedEngine(d, cfg, B, n_cap=K + S, t_cap=max(T, 1), device=dev, G=G, nn_mode=nn_mode, fwd_mode=fwd_mode)
+            eng = BatchedEngine(d, cfg, B, n_cap=K + S, t_cap=max(T, 1), device=dev, G=G, nn_mode=nn_mode, gemm_mode=gemm_mode)
         # slots of different sizes: slot b drops 7*b samples and 3*b targets
         Kb, Sb, Tb = K, max(S - 7 * b, 0), max(T - 3 * b, 0)
         src = cloud(Kb + Sb, 100 + b)
@@ -658,21 +658,28 @@ def test_engine_nn_shapes_are_bit_identical(dev):
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
 
 
+@pytest.mark.parametrize("gemm_mode", [1, 2, 3])
 @pytest.mark.parametrize("tag", ["se3aa", "sim3eu", "sflow"])
-def test_engine_forward_on_bf16_splits_stays_inside_the_parity_budget(dev, tag):
-    """Opt-in fwd_mode 1 (two 128x128 layers from three-way bf16 splits on the bf16 MFMA): the SAME tolerances against the oracle as
-    the default forward -- loss to 1e-4 relative, warped points to 1e-4 -- and activations within 2e-6 of the default forward's
-    (both are ~5e-7 of the output scale away from a float64 evaluation)."""
-    eng, states, refs = _engine_vs_oracle(dev, tag, K=0, S=300, T=280, m=2, iters=6, early_stop=False, w_cd=1.0, trunc=1e9, fwd_mode=1)
-    assert eng.c_engine.fwd_mode == 1
+def test_engine_on_bf16_splits_stays_inside_the_parity_budget(dev, tag, gemm_mode):
+    """Opt-in gemm_mode mask (1 forward, 2 bwd1, 4 bwd2: their 128x128 contractions from three-way bf16 splits on the bf16 MFMA): the
+    SAME tolerances against the oracle as the default kernels -- loss to 1e-4 relative, warped points to 1e-4, the bulk of the
+    parameters after 12 Adam steps -- and, for the forward, activations within 2e-6 of the default forward's (both are ~5e-7 of the
+    output scale away from a float64 evaluation)."""
+    eng, states, refs = _engine_vs_oracle(dev, tag, K=0, S=300, T=280, m=2, iters=6, early_stop=False, w_cd=1.0, trunc=1e9, gemm_mode=gemm_mode)
+    assert eng.c_engine.gemm_mode == gemm_mode
+    P = eng.P
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert st.level == 2 and list(st.evals_per_level[:2]) == [6, 6] and st.total_steps == 12
         assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
         assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+        diff = np.abs(eng.params[b, :, :P].cpu().numpy().reshape(-1) - ref["params_all"])
+        assert np.mean(diff < 1e-4) > 0.97, np.mean(diff < 1e-4)
+    if not gemm_mode & 1:
+        return
     # one tick of both forwards on the same state: activations side by side
     acts = []
     for mode in (0, 1):
-        e2, _, _ = _engine_vs_oracle(dev, tag, K=0, S=300, T=280, m=2, iters=1, early_stop=False, w_cd=1.0, trunc=1e9, B=1, fwd_mode=mode)
+        e2, _, _ = _engine_vs_oracle(dev, tag, K=0, S=300, T=280, m=2, iters=1, early_stop=False, w_cd=1.0, trunc=1e9, B=1, gemm_mode=mode)
         acts.append((e2.act.clone(), e2.heads.clone()))
     scale = acts[0][0].abs().max().item()
     assert (acts[0][0] - acts[1][0]).abs().max().item() < 2e-6 * max(scale, 1.0)

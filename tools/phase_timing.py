@@ -65,7 +65,7 @@ for lo, n, tag in ((36, wg_grad, "loss gradient workgroup"), (48, wg_dec, "loss 
         if buf[i]:
             print(f"   {lnames.get(i, i):36s} {buf[i] / n:9.0f}  {100.0 * buf[i] / tot:5.1f} %")
 
-if os.environ.get("NDP_FWD_MODE") == "1":
+if int(os.environ.get("NDP_GEMM_MODE", "0")) & 1:
     f8 = ["-", "layer 0 (VALU) + split + planes + h0 store", "barrier", "-", "layer 1 MFMA + epilogue", "barrier", "-",
           "layer 2 MFMA + epilogue", "barrier", "heads (waves 0..3)", "-"]
     tot = sum(buf[12 + i] for i in range(11))
