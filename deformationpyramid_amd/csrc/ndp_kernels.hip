@@ -2403,6 +2403,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (e->gemm_mode < 0 || e->gemm_mode > 7) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on bf16 splits");
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd8Bytes)) return rc;
+    if (e->gemm_mode & 4) if (int rc = set_smem((const void *)k_eng_bwd2_8, kSmemBwd8Bytes)) return rc;
     const dim3 g_nn(nn1_row_chunks(e->t_cap), e->B);
     const dim3 g_nn_lat(e->n_cap / 64 + e->t_cap / 64, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
@@ -2422,7 +2423,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);
         else if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, nn_lds, s, *e, parity, stage_x);
         NDP_EV(); hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
-        NDP_EV(); hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
+        NDP_EV();
+        if (e->gemm_mode & 4) hipLaunchKernelGGL(k_eng_bwd2_8, g_fwd8, dim3(512), kSmemBwd8Bytes, s, *e, parity);
+        else hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV();
         if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd8Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);

@@ -658,7 +658,7 @@ def test_engine_nn_shapes_are_bit_identical(dev):
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
 
 
-@pytest.mark.parametrize("gemm_mode", [1, 2, 3])
+@pytest.mark.parametrize("gemm_mode", [1, 2, 4, 7])
 @pytest.mark.parametrize("tag", ["se3aa", "sim3eu", "sflow"])
 def test_engine_on_bf16_splits_stays_inside_the_parity_budget(dev, tag, gemm_mode):
     """Opt-in gemm_mode mask (1 forward, 2 bwd1, 4 bwd2: their 128x128 contractions from three-way bf16 splits on the bf16 MFMA): the
