@@ -247,7 +247,7 @@ k_exp_dense_f32(const float *W, const float *b, const float *hin, float *hout, i
 // With lane 4 j + q of a group pointing at row p0 + j, columns c0 + 4 q .. + 3, lane l ends up with column c0 + (l & 15) of rows
 // p0 .. p0 + 3 -- any row stride works, so ONE set of row-major planes serves every contraction of the backward.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 tr_frag(const __bf16 *plane, int ks, int f0, int lane) {
+__device__ __forceinline__ bf16x8 xp_tr_frag(const __bf16 *plane, int ks, int f0, int lane) {
     const int lam = lane & 15, g = (lane >> 4) & 1, p0 = 16 * ks + 8 * (lane >> 5);
     const __bf16 *a = plane + (p0 + (lam >> 2)) * XP_ROW + f0 + 16 * g + 4 * (lam & 3);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)a);
@@ -301,9 +301,9 @@ k_exp_wgrad_bf16x3(const float *dz, const float *hin, float *gpart /*[grid][128]
             bf16x8 A[3], B[2][3];
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
-                A[s] = tr_frag(pz + s * XP_PLANE, ks, 32 * ob, lane);
-                B[0][s] = tr_frag(ph + s * XP_PLANE, ks, 32 * kb, lane);
-                B[1][s] = tr_frag(ph + s * XP_PLANE, ks, 32 * kb + 32, lane);
+                A[s] = xp_tr_frag(pz + s * XP_PLANE, ks, 32 * ob, lane);
+                B[0][s] = xp_tr_frag(ph + s * XP_PLANE, ks, 32 * kb, lane);
+                B[1][s] = xp_tr_frag(ph + s * XP_PLANE, ks, 32 * kb + 32, lane);
             }
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
