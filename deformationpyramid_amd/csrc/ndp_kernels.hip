@@ -2399,7 +2399,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (nn && e->nn_mode != 0 && e->nn_mode != 1) return fail(NDP_E_INVALID, "ndp_engine_run: nn_mode must be 0 (one pass) or 1 (latency shape)");
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
-    const dim3 g_fwd8(e->G > 1 ? e->G / 2 : 1, e->B);              // one 8-wave workgroup per CU: half as many, twice the tiles each
+    // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
+    // partials per pair); in a mixed configuration they take half the fp32 grid and zero the partials they do not write.
+    const dim3 g_fwd8(e->gemm_mode == 7 ? e->G : (e->G > 1 ? e->G / 2 : 1), e->B);
     if (e->gemm_mode < 0 || e->gemm_mode > 7) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on bf16 splits");
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd8Bytes)) return rc;

@@ -51,7 +51,10 @@ class BatchedEngine:
         self.P = desc.param_count
         self.p_stride = (self.P + 63) // 64 * 64
         tiles = self.n_cap // N.TILE
-        self.G = int(G) if G else max(1, min(tiles, -(-512 // B)))
+        # workgroups per pair in the level kernels: two 4-wave workgroups per CU (fp32 kernels) or, when all three level kernels run
+        # on bf16 splits, one 8-wave workgroup per CU -- then also half as many gradient partials to write and to fold
+        per_cu = 1 if self.gemm_mode == 7 else 2
+        self.G = int(G) if G else max(1, min(tiles, -(-256 * per_cu // B)))
         d = self.device
         f32 = dict(device=d, dtype=torch.float32)
         m = cfg.m
