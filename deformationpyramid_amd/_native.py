@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIBDIR = os.path.join(_HERE, "lib")
 LIBPATH = os.path.join(LIBDIR, "libndp_hip.so")
 SOURCES = ["ndp_kernels.hip"]
-HEADERS = ["ndp_device.h", "ndp_nerfies.inc", "ndp_ed.inc", "ndp_fwd_bf16.inc", "ndp_bwd_bf16.inc", os.path.join("..", "..", "include", "ndp_hip.h"), os.path.join("..", "..", "include", "ndp_types.h")]
+HEADERS = ["ndp_device.h", "ndp_nerfies.inc", "ndp_ed.inc", "ndp_fwd_bf16.inc", "ndp_bwd_bf16.inc", "ndp_nn_matrix.inc", os.path.join("..", "..", "include", "ndp_hip.h"), os.path.join("..", "..", "include", "ndp_types.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 NDP_MAX_LEVELS = 16
@@ -150,6 +150,8 @@ _SIGS = {
     "ndp_nerfies_bwd": [V, V, I, V, V, V, V, V, V, I, I, V],
     "ndp_chamfer_nn_fwd": [V, I, V, I, V, V, V, V, V],
     "ndp_chamfer_nn_onepass": [V, I, V, I, V, V, V, V, V, V],
+    "ndp_chamfer_nn_matrix": [V, I, V, I, V, V, V, V, V, V],
+    "ndp_engine_nn_matrix_fits": [I],
     "ndp_chamfer_l1_bwd": [V, I, V, I, F, V, V, V, V, V, V, I, V],
     "ndp_flow_metrics": [V, V, V, I, V, V],
     "ndp_landmark_mse_fwd_bwd": [V, V, I, V, V, V],

@@ -1512,6 +1512,8 @@ k_nn1_rows(int S, int T, int n_cap, const float *ws_row, float *d2x, int *idx_x)
     idx_x[i] = r.idx;
 }
 
+#include "ndp_nn_matrix.inc"
+
 // Loss, early-stop decision and dL/dx' for every pair (one launch per tick).
 //   last workgroup of a pair: loss (registration.py:193-212; loss.py:185-258), the stop rule in double
 //                     (registration.py:226-232) and the pair's next state;
@@ -2396,7 +2398,12 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     if (nn) if (int rc = set_smem((const void *)k_eng_nn, nn_lds)) return rc;
-    if (nn && e->nn_mode != 0 && e->nn_mode != 1) return fail(NDP_E_INVALID, "ndp_engine_run: nn_mode must be 0 (one pass) or 1 (latency shape)");
+    if (nn && (e->nn_mode < 0 || e->nn_mode > 2))
+        return fail(NDP_E_INVALID, "ndp_engine_run: nn_mode must be 0 (one pass, vector pipe), 1 (latency shape) or 2 (one pass, matrix pipe)");
+    if (nn && e->nn_mode == 2) {
+        if (!nn2_fits(e->n_cap)) return fail(NDP_E_UNSUPPORTED, "ndp_engine_run: n_cap too large for nn_mode 2 (sources + column table must fit LDS)");
+        if (int rc = set_smem((const void *)k_eng_nn_mx, nn2_lds_floats(e->n_cap) * 4)) return rc;
+    }
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
     // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
@@ -2423,6 +2430,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         else hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         NDP_EV();
         if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);
+        else if (nn && e->nn_mode == 2) hipLaunchKernelGGL(k_eng_nn_mx, g_nn, blk, nn2_lds_floats(e->n_cap) * 4, s, *e, parity);
         else if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, nn_lds, s, *e, parity, stage_x);
         NDP_EV(); hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         NDP_EV();
@@ -2461,6 +2469,22 @@ extern "C" int ndp_chamfer_nn_onepass(const float *x, int S, const float *y, int
     HIP_TRY(hipGetLastError(), "k_nn1 launch");
     return 0;
 }
+
+extern "C" int ndp_chamfer_nn_matrix(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y,
+                                     int *idx_y, float *ws_row, void *stream) {
+    if (S <= 0 || T <= 0 || !x || !y || !d2x || !idx_x || !d2y || !idx_y || !ws_row)
+        return fail(NDP_E_INVALID, "ndp_chamfer_nn_matrix: bad arguments");
+    const int n_cap = (S + NDP_TILE - 1) / NDP_TILE * NDP_TILE;
+    if (!nn2_fits(n_cap)) return fail(NDP_E_UNSUPPORTED, "ndp_chamfer_nn_matrix: S too large (sources + column table must fit LDS)");
+    const int lds = nn2_lds_floats(n_cap) * 4;
+    if (int rc = set_smem((const void *)k_nn2, lds)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_nn2, dim3((T + NN1_YCH - 1) / NN1_YCH), dim3(256), lds, s, x, S, y, T, n_cap, ws_row, d2y, idx_y);
+    hipLaunchKernelGGL(k_nn1_rows, dim3((S + 255) / 256), dim3(256), 0, s, S, T, n_cap, ws_row, d2x, idx_x);
+    HIP_TRY(hipGetLastError(), "k_nn2 launch");
+    return 0;
+}
+extern "C" int ndp_engine_nn_matrix_fits(int n_cap) { return nn2_fits(n_cap) ? 1 : 0; }
 
 extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream) {
     return engine_launch_ticks(e, tick0, n_ticks, (hipStream_t)stream, nullptr);

@@ -139,8 +139,9 @@ def chamfer_nn(x, y):
     return d2x, ix, d2y, iy
 
 
-def chamfer_nn_onepass(x, y):
-    """Same result as chamfer_nn from one pass over the S x T distances (the engine's per-tick kernels as an operator)."""
+def chamfer_nn_onepass(x, y, matrix=False):
+    """Same result as chamfer_nn from one pass over the S x T distances (the engine's per-tick kernels as an operator);
+    matrix: the variant that forms the distances on the bf16 matrix pipe and re-evaluates the candidates exactly (engine nn_mode 2)."""
     _chk(x, "x"); _chk(y, "y")
     S, T = x.shape[0], y.shape[0]
     nr = ctypes.c_longlong()
@@ -148,8 +149,9 @@ def chamfer_nn_onepass(x, y):
     ws_row = torch.empty(nr.value, device=x.device)
     d2x = torch.empty(S, device=x.device); d2y = torch.empty(T, device=x.device)
     ix = torch.empty(S, device=x.device, dtype=torch.int32); iy = torch.empty(T, device=x.device, dtype=torch.int32)
-    N.check(N.lib().ndp_chamfer_nn_onepass(_p(x), S, _p(y), T, _p(d2x), _p(ix), _p(d2y), _p(iy), _p(ws_row),
-                                           N.stream_ptr(x.device)), "ndp_chamfer_nn_onepass")
+    fn = N.lib().ndp_chamfer_nn_matrix if matrix else N.lib().ndp_chamfer_nn_onepass
+    N.check(fn(_p(x), S, _p(y), T, _p(d2x), _p(ix), _p(d2y), _p(iy), _p(ws_row), N.stream_ptr(x.device)),
+            "ndp_chamfer_nn_matrix" if matrix else "ndp_chamfer_nn_onepass")
     return d2x, ix, d2y, iy
 
 

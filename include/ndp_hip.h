@@ -149,6 +149,15 @@ int ndp_chamfer_nn_fwd(const float *x, int S, const float *y, int T,
 int ndp_chamfer_nn_onepass(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y,
                            int *idx_y, float *ws_row, void *stream);
 
+/* The one-pass result with the S x T distances on the bf16 MATRIX pipe (the engine's nn_mode 2): |x - y|^2 = |x|^2 + |y|^2 - 2 x.y as
+ * one contraction per 32 x 32 tile, every term a three-way bf16 split (two v_mfma_f32_32x32x16_bf16 per 1024 distances); that value
+ * only SELECTS candidates -- every candidate within the rounding bound is re-evaluated with the exact fma chain, so d2 and the lowest
+ * index are bit-identical to ndp_chamfer_nn_fwd.  S is limited by LDS (sources + column table: NDP_E_UNSUPPORTED beyond;
+ * ndp_engine_nn_matrix_fits(n_cap) tells).  ws_row as for ndp_chamfer_nn_onepass.                                        */
+int ndp_chamfer_nn_matrix(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y,
+                          int *idx_y, float *ws_row, void *stream);
+int ndp_engine_nn_matrix_fits(int n_cap);
+
 /* Truncated L1 Chamfer value and gradient from the NN result (loss.py:185-258 and its autograd):
  * loss[0] = sum_i sqrt(d2x_i)[d2x_i<trunc]/S + sum_j sqrt(d2y_j)[d2y_j<trunc]/T   (point_sum != 0: without the /S, /T --
  * point_reduction="sum", loss.py:233-235) ;
@@ -232,7 +241,8 @@ typedef struct ndp_engine {
     int nn_mode, gemm_mode;          /* gemm_mode 0 (default): level kernels on the fp32 MFMA, bitwise the oracle's fma chain.  OPT-IN
                                         mask: 1 forward, 2 bwd1, 4 bwd2 with their 128 x 128 contractions as three-way bf16 splits
                                         on the bf16 MFMA -- fp32-level accuracy, not bitwise the chain (csrc/ndp_*_bf16.inc).
-                                        nn_mode 0: one-pass kernel (throughput, many pairs resident); 1: latency shape -- two passes in
+                                        nn_mode 0: one-pass kernel, distances on the vector pipe; 2: the same on the bf16 matrix pipe with exact re-evaluation
+                                        (bit-identical, needs ndp_engine_nn_matrix_fits(n_cap));  0: one-pass kernel (throughput, many pairs resident); 1: latency shape -- two passes in
                                         64-query workgroups, S/64 + T/64 of them per pair -- for a handful of resident pairs   */
 } ndp_engine;
 

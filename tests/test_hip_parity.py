@@ -607,7 +607,8 @@ def test_chamfer_nn_is_exact_on_adversarial_layouts(dev, name):
 
 @pytest.mark.parametrize("name", ["clusters", "far_queries", "plane", "line", "lattice_ties", "single_ref", "identical",
                                   "skewed", "large", "ragged", "near_ties"])
-def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name):
+@pytest.mark.parametrize("matrix", [False, True])
+def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name, matrix):
     """The engine's one-pass kernels (every distance evaluated once, column minima by cross-lane butterflies, second-stage
     fold) must give the bits of the two-pass brute force: d2 and lowest index, both directions."""
     from deformationpyramid_amd import ops
@@ -626,14 +627,14 @@ def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name):
         cases = [_nn_case(name)]
     for x, y in cases:
         r = O().chamfer(x.numpy(), y.numpy(), want_grad=False, nthreads=8)
-        d2x, ix, d2y, iy = [t.cpu().numpy() for t in ops.chamfer_nn_onepass(x.to(dev), y.to(dev))]
+        d2x, ix, d2y, iy = [t.cpu().numpy() for t in ops.chamfer_nn_onepass(x.to(dev), y.to(dev), matrix=matrix)]
         np.testing.assert_array_equal(d2x, r["d2x"])
         np.testing.assert_array_equal(d2y, r["d2y"])
         np.testing.assert_array_equal(ix, r["idx_x"])
         np.testing.assert_array_equal(iy, r["idx_y"])
 
 
-@pytest.mark.parametrize("nn_mode", [0, 1])
+@pytest.mark.parametrize("nn_mode", [0, 1, 2])
 def test_engine_matches_oracle_at_the_bench_geometry(dev, nn_mode):
     """What bench.py times: S = T = 2000 samples, G = 4 workgroups per pair, 8 resident pairs of slightly different sizes,
     3 iterations x 2 levels -- with the one-pass nearest-neighbour kernel (nn_mode 0, the throughput shape) and with the
@@ -648,14 +649,15 @@ def test_engine_matches_oracle_at_the_bench_geometry(dev, nn_mode):
 
 
 def test_engine_nn_shapes_are_bit_identical(dev):
-    """The two nearest-neighbour shapes of the engine must produce the same bits (losses, parameters) tick for tick."""
+    """The three nearest-neighbour shapes of the engine must produce the same bits (losses, parameters) tick for tick."""
     runs = []
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         eng, states, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=700, T=650, m=2, iters=4, early_stop=False, w_cd=1.0,
                                            trunc=0.05, B=3, nn_mode=mode)
         runs.append((eng.params.clone(), [s.loss for s in states], eng.d2y.clone(), eng.idx_y.clone()))
-    assert runs[0][1] == runs[1][1]
-    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][2], runs[1][2]) and torch.equal(runs[0][3], runs[1][3])
+    for other in runs[1:]:
+        assert runs[0][1] == other[1]
+        assert torch.equal(runs[0][0], other[0]) and torch.equal(runs[0][2], other[2]) and torch.equal(runs[0][3], other[3])
 
 
 @pytest.mark.parametrize("gemm_mode", [1, 2, 4, 7])
