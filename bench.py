@@ -226,6 +226,9 @@ def main():
     ap.add_argument("--gemm-mode", type=int, default=0, choices=list(range(8)),
                     help="0 (default): level kernels on the fp32 MFMA, bitwise the oracle's fma chain; OPT-IN mask 1 forward | 2 bwd1 | 4 bwd2: "
                          "their 128x128 contractions as three-way bf16 splits on the bf16 MFMA (fp32-level accuracy, not bitwise)")
+    ap.add_argument("--nn-mode", type=int, default=-1, choices=[-1, 0, 1, 2],
+                    help="-1 (default): the engine chooses (0 one-pass on the vector pipe at throughput sizes, 1 latency shape); 2: OPT-IN one-pass "
+                         "with the distances on the bf16 matrix pipe and exact re-evaluation (bit-identical results)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 register() latency measurement")
@@ -300,6 +303,8 @@ def main():
             pairs.append((src.to(dev), tgt.to(dev)))
         gts.append((flow_gt, overlap))
     os.environ["NDP_GEMM_MODE"] = str(args.gemm_mode)          # read by every engine this process creates
+    if args.nn_mode >= 0:
+        os.environ["NDP_NN_MODE"] = str(args.nn_mode)
     model = Registration(cfg)
     torch.manual_seed(rank)
 
@@ -358,6 +363,8 @@ def main():
                    "contraction_arithmetic": ("fp32 MFMA, bitwise the fma chain" if args.gemm_mode == 0 else
                                               f"OPT-IN mask {args.gemm_mode} (1 fwd | 2 bwd1 | 4 bwd2): 128x128 contractions as three-way bf16 "
                                               "splits on the bf16 MFMA, fp32 accumulate"),
+                   "nn_kernel": {-1: "engine default (vector pipe)", 0: "one-pass, vector pipe", 1: "latency shape",
+                                 2: "OPT-IN one-pass, distances on the bf16 matrix pipe, exact re-evaluation"}[args.nn_mode],
                    "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B * args.engines, "engines_per_gpu": args.engines, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective",
                    "backend": ("none" if not use_dist else ("rccl" if backend == "nccl" else backend)),
                    "seeds": "rank r registers synthetic_pair(r*pairs_per_step + i), i < pairs_per_step; torch.manual_seed(r) "
