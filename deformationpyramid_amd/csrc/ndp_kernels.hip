@@ -2411,7 +2411,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     const dim3 g_fwd8(e->gemm_mode == 7 ? e->G : (e->G > 1 ? e->G / 2 : 1), e->B);
     if (e->gemm_mode < 0 || e->gemm_mode > 7) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on bf16 splits");
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
-    if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd8Bytes)) return rc;
+    if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd18Bytes)) return rc;
     if (e->gemm_mode & 4) if (int rc = set_smem((const void *)k_eng_bwd2_8, kSmemBwd8Bytes)) return rc;
     const dim3 g_nn(nn1_row_chunks(e->t_cap), e->B);
     const dim3 g_nn_lat(e->n_cap / 64 + e->t_cap / 64, e->B);
@@ -2437,7 +2437,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         if (e->gemm_mode & 4) hipLaunchKernelGGL(k_eng_bwd2_8, g_fwd8, dim3(512), kSmemBwd8Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV();
-        if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd8Bytes, s, *e, parity);
+        if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd18Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV(); hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
         NDP_EV();
