@@ -103,6 +103,8 @@ class BatchedEngine:
         # few resident pairs: the one-pass kernel has only t_cap/256 workgroups per pair; the latency shape has (n_cap + t_cap)/64
         if self.nn_mode is None and os.environ.get("NDP_NN_MODE"):            # experiments (tools/tick_bench.py): force a shape
             self.nn_mode = int(os.environ["NDP_NN_MODE"])
+            if self.nn_mode == 2 and not N.lib().ndp_engine_nn_matrix_fits(self.n_cap):
+                self.nn_mode = 0                                                  # sources + column table do not fit LDS: vector kernel
         if self.nn_mode is not None:
             e.nn_mode = int(self.nn_mode)
         else:
