@@ -34,12 +34,14 @@ sys.path.insert(0, ROOT)
 
 from deformationpyramid_amd.config import load_config            # noqa: E402
 from deformationpyramid_amd.loss import compute_flow_metrics     # noqa: E402
-from deformationpyramid_amd.parallel import aggregate            # noqa: E402
+from deformationpyramid_amd.parallel import job_summary, pin_rank_to_gpu_numa   # noqa: E402
 from deformationpyramid_amd.registration import Registration     # noqa: E402
 from deformationpyramid_amd.config import Config                 # noqa: E402
 from deformationpyramid_amd.synthetic import surface_pair, synthetic_landmarks, synthetic_pair      # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md)
+BF16_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (same guide)
+SPLIT_PRODUCTS = 6                # bf16 partial products per fp32-equivalent product in the split kernels (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid)
 FLOP_FWD_PT = 68608
 FLOP_BWD_PT = 135680
 FLOP_NN_PAIR = 8                  # per (source, target) distance evaluation; one pass serves both directions
@@ -65,22 +67,89 @@ def kernel_profile(model, pairs, slots, n_ticks=24):
     return {k: v / n_ticks for k, v in zip(TICK_KERNELS, ms)}, eng, preps, active
 
 
-def pmc_traffic(kernel, pairs):
-    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled
-    per the gfx950 correction, WRITE_SIZE as is; collected by tools/pmc_traffic.sh at 128 pairs per launch and
-    scaled linearly to this launch's pair count).  None when no such profile is committed."""
+def _git_blob_hash(path):
+    """`git hash-object` of a file without git (the GPU box has no .git): sha1("blob <len>\\0" + content)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def pmc_traffic(kernels, pairs):
+    """HBM bytes per launch of the kernel(s) behind one tick stage, from the rocprofv3 PMC passes kept under profiles/
+    (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is; collected by tools/pmc_traffic.sh at 128 pairs per launch
+    and scaled linearly to this launch's pair count).  -> (bytes or None, source description or None): the figure is NOT
+    measured in this run -- `traffic_source` names the committed profile it comes from and that file's git blob hash."""
     try:
-        path = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_hbm_traffic_pmc.json"))[-1]   # newest round
-        rec = json.load(open(os.path.join(ROOT, "profiles", path)))[kernel]
-        return rec["hbm_bytes_per_launch"] * pairs / rec["pairs_per_launch"]
+        names = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_hbm_traffic_pmc.json"))
+        for name in reversed(names):                                             # newest round that has these kernels
+            path = os.path.join(ROOT, "profiles", name)
+            rec = json.load(open(path))
+            if all(k in rec for k in kernels):
+                tot = sum(rec[k]["hbm_bytes_per_launch"] * pairs / rec[k]["pairs_per_launch"] for k in kernels)
+                return tot, {"file": "profiles/" + name, "git_blob": _git_blob_hash(path), "kernels": list(kernels),
+                             "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_traffic.sh), FETCH_SIZE doubled"}
     except (OSError, KeyError, ValueError, IndexError):
-        return None
+        pass
+    return None, None
 
 
-def latency_profile(cfg, pairs, repeats=5):
+def stage_kernels(gemm_mode, nn_mode):
+    """The launches behind each of the six tick stages (N.TICK_KERNELS order) for an engine's modes."""
+    return {"k_eng_fwd": ["k_eng_fwd8", "k_eng_warp"] if gemm_mode & 1 else ["k_eng_fwd"],
+            "k_eng_nn": [{0: "k_eng_nn", 1: "k_eng_nn_lat", 2: "k_eng_nn_mx"}[nn_mode]],
+            "k_eng_loss": ["k_eng_loss"],
+            "k_eng_bwd2": ["k_eng_bwd2_8"] if gemm_mode & 4 else ["k_eng_bwd2"],
+            "k_eng_bwd1": ["k_eng_bwd1_8"] if gemm_mode & 2 else ["k_eng_bwd1"],
+            "k_eng_update": ["k_eng_update"]}
+
+
+def roofline_report(model, pairs, B, config):
+    """Roofline of the dominant kernel of one engine's tick (HIP events on the launch stream, all slots active at level 0),
+    priced against the peak of the pipe that kernel's contractions run on: the fp32 MFMA / vector peak for the bitwise kernels
+    and the nearest-neighbour kernels, the dense bf16 MFMA peak / 6 for the bf16-split level kernels (six bf16 products per
+    fp32-equivalent product: algorithmic FLOP stay SURVEY 8(d)'s)."""
+    prof, eng, preps, active = kernel_profile(model, pairs, B)
+    S, T, n = preps[0].S, preps[0].T, preps[0].S + preps[0].K       # n: points through the MLP (landmarks + samples)
+    P = eng.P
+    names = stage_kernels(eng.gemm_mode, eng.nn_mode)
+    dom = max(prof, key=prof.get)
+    nh = preps[0].desc.n_heads                                       # head rows: 6 SE3, 7 Sim3 (SURVEY 8d: +768 FLOP/pt)
+    # backward split by layer: bwd2 = heads (dWh + dh2) + dW2 + dh1, bwd1 = dW1 + dh0 + dW0 (768 MAC)
+    flops = {"k_eng_fwd": (FLOP_FWD_PT + 256 * (nh - 6)) * n, "k_eng_bwd2": 2 * (2 * 16384 + 256 * nh) * n,
+             "k_eng_bwd1": 2 * (2 * 16384 + 768) * n, "k_eng_nn": FLOP_NN_PAIR * S * T,
+             "k_eng_update": 12 * P, "k_eng_loss": 4 * (S + T)}
+    split = {"k_eng_fwd": eng.gemm_mode & 1, "k_eng_bwd1": eng.gemm_mode & 2, "k_eng_bwd2": eng.gemm_mode & 4}
+    peak_of = {k: (BF16_PEAK_TFLOPS / SPLIT_PRODUCTS if split.get(k) else FP32_PEAK_TFLOPS) for k in prof}
+    ach = flops[dom] * active / (prof[dom] * 1e-3) / 1e12
+    tick_ms = sum(prof.values())
+    traffic, src = pmc_traffic(names[dom], active) if config == "A" else (None, None)
+    roof = {"bound": "mfma", "kernel": "+".join(names[dom]), "achieved": ach, "peak": peak_of[dom], "unit": "TFLOP/s",
+            "frac": ach / peak_of[dom], "traffic": traffic, "traffic_source": src,
+            "peak_is": ("dense bf16 MFMA peak / 6 (six bf16 partial products per fp32-equivalent product)" if split.get(dom)
+                        else "fp32 MFMA = fp32 vector peak"),
+            "avg_launch_ms": prof[dom], "pairs_per_launch": active, "algorithmic_flop_per_pair_launch": flops[dom]}
+    if traffic:                                   # the other ceiling, for the record: HBM bytes/s of the same kernel vs 8 TB/s
+        roof["hbm_tbps"] = traffic / (prof[dom] * 1e-3) / 1e12
+        roof["hbm_frac"] = roof["hbm_tbps"] / 8.0
+    per_kernel = {"+".join(names[k]): {"ms": prof[k], "achieved_tflops": flops[k] * active / (prof[k] * 1e-3) / 1e12,
+                                        "frac_of_its_peak": flops[k] * active / (prof[k] * 1e-3) / 1e12 / peak_of[k]}
+                  for k in ("k_eng_fwd", "k_eng_nn", "k_eng_bwd2", "k_eng_bwd1")}
+    return {"roofline": roof, "kernels_ms_per_tick": {"+".join(names[k]): v for k, v in prof.items()}, "kernel_rooflines": per_kernel,
+            "tick": {"ms": tick_ms, "achieved_tflops": (algorithmic_flops(n, 0, P) + FLOP_NN_PAIR * S * T) * active / (tick_ms * 1e-3) / 1e12},
+            "engine_modes": {"gemm_mode": eng.gemm_mode, "nn_mode": eng.nn_mode, "G": eng.G}}
+
+
+ARITH_TEXT = {0: "fp32 MFMA, bitwise the oracle's fma chain",
+              7: "128x128 contractions of the three level kernels as three-way bf16 splits (six partial products) on the bf16 MFMA, "
+                 "fp32 accumulate: fp32-level accuracy (tests/test_split_accuracy.py), not bitwise the chain"}
+NN_TEXT = {0: "one pass, distances on the vector pipe", 1: "latency shape (two passes, 64-query workgroups)",
+           2: "one pass, distances on the bf16 matrix pipe + exact re-evaluation (bit-identical results)"}
+
+
+def latency_profile(cfg, pairs, repeats=5, gemm_mode=None):
     """Batch 1 -- what the reference API is (one pair per register() call, /root/reference/eval_nolearned.py:89-93):
     wall time of Registration.register() on single 8192-pt pairs, and the per-kernel split of one tick at B = 1."""
-    model = Registration(cfg)
+    model = Registration(cfg, gemm_mode=gemm_mode)
     torch.manual_seed(0)
     dev = model._dev()
     walls, iters = [], []
@@ -105,7 +174,7 @@ def latency_profile(cfg, pairs, repeats=5):
     return {"ms_per_pair": 1e3 * walls[med], "adam_iters": int(iters[med]), "ms_per_iter": 1e3 * walls[med] / max(iters[med], 1),
             "ms_per_pair_all": [round(1e3 * w, 2) for w in walls], "workgroups_per_level_kernel": eng.G,
             "kernels_ms_per_tick": {k: v / n_ticks for k, v in zip(TICK_KERNELS, ms)},
-            "tick_ms": sum(ms) / n_ticks}
+            "tick_ms": sum(ms) / n_ticks, "gemm_mode": eng.gemm_mode, "nn_mode": eng.nn_mode}
 
 
 def _cpu_info():
@@ -223,12 +292,16 @@ def main():
                          "D Sim3/euler, 6000 samples of 24 856-pt clouds (shape transfer); E LNDP.yaml, 500 landmarks, m = 10")
     ap.add_argument("--fixed-work", action="store_true",
                     help="SURVEY 8(d) config B: early stop off, 50 iterations x 9 levels = 450 Adam steps per pair")
-    ap.add_argument("--gemm-mode", type=int, default=0, choices=list(range(8)),
-                    help="0 (default): level kernels on the fp32 MFMA, bitwise the oracle's fma chain; OPT-IN mask 1 forward | 2 bwd1 | 4 bwd2: "
-                         "their 128x128 contractions as three-way bf16 splits on the bf16 MFMA (fp32-level accuracy, not bitwise)")
+    ap.add_argument("--gemm-mode", type=int, default=-1, choices=list(range(-1, 8)),
+                    help="-1 (default): the engine's default arithmetic (engine.DEFAULT_GEMM_MODE); 0: level kernels on the fp32 MFMA, "
+                         "bitwise the oracle's fma chain; mask 1 forward | 2 bwd1 | 4 bwd2 (7 = all): their 128x128 contractions as "
+                         "three-way bf16 splits on the bf16 MFMA (fp32-level accuracy, not bitwise)")
     ap.add_argument("--nn-mode", type=int, default=-1, choices=[-1, 0, 1, 2],
-                    help="-1 (default): the engine chooses (0 one-pass on the vector pipe at throughput sizes, 1 latency shape); 2: OPT-IN one-pass "
-                         "with the distances on the bf16 matrix pipe and exact re-evaluation (bit-identical results)")
+                    help="-1 (default): the engine chooses (one-pass kernel at throughput sizes -- on the matrix pipe when "
+                         "engine.DEFAULT_NN_MATRIX -- latency shape for a few pairs); 0 one-pass on the vector pipe; 1 latency shape; "
+                         "2 one-pass with the distances on the bf16 matrix pipe and exact re-evaluation (bit-identical results)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the second measurement in the other arithmetic configuration")
+    ap.add_argument("--alt-steps", type=int, default=2, help="timed steps of the second measurement (1 warm-up step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the batch-1 register() latency measurement")
@@ -261,8 +334,16 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     n_gpus = max(world, 1)
+    if use_dist:
+        import torch.distributed as dist
+        if dist.get_world_size() != max(args.gpus, 1):
+            sys.exit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    # one process per GPU: keep this rank (main thread, pair producer, torch's few host threads) on the CPUs of its GPU's NUMA
+    # node, in a slice of its own (8 ranks x 2-3 busy threads otherwise migrate across sockets)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(n_gpus)))
+    placement = pin_rank_to_gpu_numa(local_rank if backend != "gloo" else int(os.environ.get("LOCAL_RANK", "0")), local_world) if n_gpus > 1 else None
     torch.set_num_threads(max(1, min(8, (os.cpu_count() or 8) // n_gpus)))   # host plumbing only; more threads hurt
 
     cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=local_rank)
@@ -302,11 +383,6 @@ def main():
         else:
             pairs.append((src.to(dev), tgt.to(dev)))
         gts.append((flow_gt, overlap))
-    os.environ["NDP_GEMM_MODE"] = str(args.gemm_mode)          # read by every engine this process creates
-    if args.nn_mode >= 0:
-        os.environ["NDP_NN_MODE"] = str(args.nn_mode)
-    model = Registration(cfg)
-    torch.manual_seed(rank)
 
     def barrier():
         if use_dist:
@@ -314,41 +390,48 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def step():
-        return model.register_batch(pairs, slots=B, chunk=args.chunk, engines=args.engines)
+    def timed_run(model, steps, warmup):
+        """`warmup` untimed + exactly `steps` timed register_batch passes over the resident pairs, bracketed by barrier + synchronize."""
+        torch.manual_seed(rank)
+        for _ in range(warmup):
+            model.register_batch(pairs, slots=B, chunk=args.chunk, engines=args.engines)
+        barrier()
+        t0 = time.perf_counter()
+        n_steps = n_evals = 0
+        last = None
+        for _ in range(steps):
+            last = model.register_batch(pairs, slots=B, chunk=args.chunk, engines=args.engines)
+            n_steps += sum(s.total_steps for s in model.last_states)
+            n_evals += sum(s.total_evals for s in model.last_states)
+        barrier()
+        return time.perf_counter() - t0, n_steps, n_evals, last
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    steps_total = evals_total = 0
-    last = None
-    for _ in range(args.steps):
-        last = step()
-        steps_total += sum(s.total_steps for s in model.last_states)
-        evals_total += sum(s.total_evals for s in model.last_states)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def accuracy_sums(last):
+        keys = msum = None
+        for (warped, _), item, (flow_gt, overlap) in zip(last, pairs, gts):
+            mtr = compute_flow_metrics(warped - item[0], flow_gt.to(dev), overlap.to(dev))
+            keys = list(mtr.keys())
+            v = np.array([mtr[k] for k in keys], dtype=np.float64)
+            msum = v if msum is None else msum + v
+        return keys, msum
 
-    # accuracy of the last step's pairs (not timed)
-    keys = None
-    msum = None
-    for (warped, _), item, (flow_gt, overlap) in zip(last, pairs, gts):
-        mtr = compute_flow_metrics(warped - item[0], flow_gt.to(dev), overlap.to(dev))
-        keys = list(mtr.keys())
-        v = np.array([mtr[k] for k in keys], dtype=np.float64)
-        msum = v if msum is None else msum + v
+    model = Registration(cfg, gemm_mode=None if args.gemm_mode < 0 else args.gemm_mode, nn_mode=None if args.nn_mode < 0 else args.nn_mode)
+    elapsed, steps_total, evals_total, last = timed_run(model, args.steps, args.warmup)
+    eng0 = model._engines[0]
+    main_modes = (eng0.gemm_mode, eng0.nn_mode)
+    keys, msum = accuracy_sums(last)                          # accuracy of the last step's pairs (not timed)
 
-    vals = torch.tensor([float(args.steps * NP), float(steps_total), float(evals_total)] + list(msum) + [float(NP)],
-                        dtype=torch.float64)
-    agg, elapsed = aggregate(vals, elapsed, torch.device("cpu") if backend == "gloo" else dev)   # the single collective: SUM + MAX (RCCL)
-    agg = agg.numpy()
-    n_pairs, n_steps, n_evals = agg[0], agg[1], agg[2]
-    metrics = {k: float(v / agg[-1]) for k, v in zip(keys, agg[3:-1])}
+    # the single collective (RCCL): one SUM all-reduce carries the sums, every rank's pair count and every rank's elapsed time
+    job = job_summary(args.steps * NP, elapsed, [float(steps_total), float(evals_total)] + list(msum) + [float(NP)],
+                      torch.device("cpu") if backend == "gloo" else dev)
+    n_pairs, elapsed = job["pairs"], job["elapsed"]
+    sums = job["sums"].numpy()
+    n_steps, n_evals = sums[0], sums[1]
+    metrics = {k: float(v / sums[-1]) for k, v in zip(keys, sums[2:-1])}
 
     out = {
         "metric": "point-cloud pairs/sec (8192-pt NDP registration)",
-        "value": n_pairs / elapsed,
+        "value": job["value"],
         "unit": "pairs/s",
         "n_gpus": n_gpus,
         "steps": args.steps,
@@ -360,11 +443,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "survey_8d_config": args.config,
-                   "contraction_arithmetic": ("fp32 MFMA, bitwise the fma chain" if args.gemm_mode == 0 else
-                                              f"OPT-IN mask {args.gemm_mode} (1 fwd | 2 bwd1 | 4 bwd2): 128x128 contractions as three-way bf16 "
-                                              "splits on the bf16 MFMA, fp32 accumulate"),
-                   "nn_kernel": {-1: "engine default (vector pipe)", 0: "one-pass, vector pipe", 1: "latency shape",
-                                 2: "OPT-IN one-pass, distances on the bf16 matrix pipe, exact re-evaluation"}[args.nn_mode],
+                   "contraction_arithmetic": ARITH_TEXT.get(main_modes[0], f"mask {main_modes[0]} (1 fwd | 2 bwd1 | 4 bwd2) on bf16 splits, the rest on the fp32 MFMA"),
+                   "nn_kernel": NN_TEXT[main_modes[1]], "gemm_mode": main_modes[0], "nn_mode": main_modes[1],
                    "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B * args.engines, "engines_per_gpu": args.engines, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective",
                    "backend": ("none" if not use_dist else ("rccl" if backend == "nccl" else backend)),
                    "seeds": "rank r registers synthetic_pair(r*pairs_per_step + i), i < pairs_per_step; torch.manual_seed(r) "
@@ -373,31 +453,36 @@ def main():
         "adam_iters_per_pair": n_steps / n_pairs,
         "loss_evals_per_pair": n_evals / n_pairs,
         "accuracy": metrics,
+        "world_size": job["world_size"],
+        "ranks": {"pairs_per_s_min": job["rank_pairs_per_s_min"], "pairs_per_s_max": job["rank_pairs_per_s_max"],
+                  "elapsed_s": [round(t, 4) for t in job["elapsed_per_rank"]], "allreduce_ms": job["allreduce_ms"],
+                  "cpu_placement_rank0": placement},
     }
 
-    if rank == 0 and n_gpus == 1 and not args.no_roofline:
-        prof, eng, preps, active = kernel_profile(model, pairs, B)
-        S, T, n = preps[0].S, preps[0].T, preps[0].S + preps[0].K       # n: points through the MLP (landmarks + samples)
-        P = eng.P
-        dom = max(prof, key=prof.get)
-        nh = preps[0].desc.n_heads                                       # head rows: 6 SE3, 7 Sim3 (+768 FLOP/pt)
-        # backward split by layer: bwd2 = heads (dWh + dh2) + dW2 + dh1, bwd1 = dW1 + dh0 + dW0 (768 MAC)
-        flops = {"k_eng_fwd": (FLOP_FWD_PT + 256 * (nh - 6)) * n, "k_eng_bwd2": 2 * (2 * 16384 + 256 * nh) * n,
-                 "k_eng_bwd1": 2 * (2 * 16384 + 768) * n, "k_eng_nn": FLOP_NN_PAIR * S * T,
-                 "k_eng_update": 12 * P, "k_eng_loss": 4 * (S + T)}
-        ach = flops[dom] * active / (prof[dom] * 1e-3) / 1e12
-        tick_ms = sum(prof.values())
-        traffic = pmc_traffic(dom, active) if args.config == "A" else None
-        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": ach / FP32_PEAK_TFLOPS, "traffic": traffic,
-                           "avg_launch_ms": prof[dom], "pairs_per_launch": active,
-                           "algorithmic_flop_per_pair_launch": flops[dom]}
-        if traffic:                                   # the other ceiling, for the record: HBM bytes/s of the same kernel vs 8 TB/s
-            out["roofline"]["hbm_tbps"] = traffic / (prof[dom] * 1e-3) / 1e12
-            out["roofline"]["hbm_frac"] = out["roofline"]["hbm_tbps"] / 8.0
-        out["kernels_ms_per_tick"] = prof
-        out["tick"] = {"ms": tick_ms, "achieved_tflops": (algorithmic_flops(n, 0, P) + FLOP_NN_PAIR * S * T) * active / (tick_ms * 1e-3) / 1e12}
-    if rank == 0 and n_gpus == 1 and not args.no_roofline and args.config == "A":
+    single = rank == 0 and n_gpus == 1
+    if single and not args.no_roofline:
+        out.update(roofline_report(model, pairs, B, args.config))
+    if single and not args.no_alt and args.config == "A" and main_modes[0] in (0, 7):
+        # the same workload in the OTHER arithmetic configuration, on a shorter step count: both numbers in one line
+        alt_kw = dict(gemm_mode=7, nn_matrix=True) if main_modes[0] == 0 else dict(gemm_mode=0, nn_matrix=False)
+        alt_model = Registration(cfg, **alt_kw)
+        a_elapsed, a_steps, a_evals, a_last = timed_run(alt_model, args.alt_steps, 1)
+        a_eng = alt_model._engines[0]
+        a_keys, a_msum = accuracy_sums(a_last)
+        alt = {"name": "split (bf16x3 level kernels + matrix-pipe NN)" if main_modes[0] == 0 else "bitwise (fp32-MFMA level kernels + vector-pipe NN)",
+               "value": args.alt_steps * NP / a_elapsed, "unit": "pairs/s", "steps": args.alt_steps, "warmup": 1,
+               "ms_per_step": 1e3 * a_elapsed / args.alt_steps, "ms_per_iter": 1e3 * a_elapsed / max(a_steps, 1),
+               "adam_iters_per_pair": a_steps / (args.alt_steps * NP), "dtype": "f32",
+               "contraction_arithmetic": ARITH_TEXT[a_eng.gemm_mode], "nn_kernel": NN_TEXT[a_eng.nn_mode],
+               "gemm_mode": a_eng.gemm_mode, "nn_mode": a_eng.nn_mode,
+               "accuracy": {k: float(v / NP) for k, v in zip(a_keys, a_msum)}}
+        if not args.no_roofline:
+            alt.update(roofline_report(alt_model, pairs, B, args.config))
+        out["alt"] = alt
+        if main_modes[0] == 0:
+            out["optin"] = alt                                  # (the name VERDICT r02 asked for while the split path was opt-in)
+        del alt_model
+    if single and not args.no_roofline and args.config == "A":
         # accuracy on pairs NDP actually solves: 8 partial-overlap SURFACE pairs (tests/golden/F10b holds the reference's
         # own rows: full-EPE 6.1, AccS 35.6 %, AccR 62.6 %; zero flow: EPE 13.4, AccS 0.8 %) -- not timed
         sp = [surface_pair(p) for p in range(8)]
@@ -411,9 +496,9 @@ def main():
         out["accuracy_surface_pairs"] = dict({k: float(x / 8) for k, x in zip(mtr.keys(), acc)},
                                              reference={"full-epe": 6.12, "full-AccS": 35.6, "full-AccR": 62.6},
                                              zero_flow={"full-epe": 13.36, "full-AccS": 0.83})
-    if rank == 0 and n_gpus == 1 and not args.no_latency and args.config == "A":
-        out["latency"] = latency_profile(cfg, pairs)
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and args.config == "A":
+    if single and not args.no_latency and args.config == "A":
+        out["latency"] = latency_profile(cfg, pairs, gemm_mode=main_modes[0])
+    if single and not args.no_cpu_baseline and args.config == "A":
         out["cpu_baseline"] = cpu_baseline(cfg, pairs)
     if rank == 0:
         print(json.dumps(out))

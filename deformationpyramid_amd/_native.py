@@ -85,26 +85,32 @@ def source_id():
     ndp_engine / ndp_load_job are passed BY VALUE into kernels and a stale layout would corrupt device memory."""
     import hashlib
     h = hashlib.sha256()
-    for d in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, x)) for x in HEADERS]:
-        with open(d, "rb") as f:
-            h.update(f.read())
+    try:
+        for d in [os.path.join(CSRC, s) for s in SOURCES] + [os.path.normpath(os.path.join(CSRC, x)) for x in HEADERS]:
+            with open(d, "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None                      # a deployment without csrc/: the prebuilt library's embedded id stands (see _stale)
     h.update(" ".join(HIPCC_FLAGS).encode())
     return h.hexdigest()[:16]
 
 
-def _built_id(path):
+def _built_id(path, tag=b"NDP_BUILD_ID"):
     """Build id of an existing library file (the tag string ndp_build_id() returns, found without loading it), or None."""
     import re
     try:
         with open(path, "rb") as f:
-            hit = re.search(rb"NDP_BUILD_ID=([0-9a-f]{16})", f.read())
+            hit = re.search(tag + rb"=([0-9a-f]{16})", f.read())
         return hit.group(1).decode() if hit else None
     except OSError:
         return None
 
 
 def _stale():
-    return not os.path.exists(LIBPATH) or _built_id(LIBPATH) != source_id()
+    sid = source_id()
+    if sid is None:                      # no sources to compare with: any library that carries an id is taken as built
+        return _built_id(LIBPATH) is None
+    return not os.path.exists(LIBPATH) or _built_id(LIBPATH) != sid
 
 
 def build(force=False, verbose=False):
@@ -152,12 +158,14 @@ _SIGS = {
     "ndp_chamfer_nn_onepass": [V, I, V, I, V, V, V, V, V, V],
     "ndp_chamfer_nn_matrix": [V, I, V, I, V, V, V, V, V, V],
     "ndp_engine_nn_matrix_fits": [I],
+    "ndp_engine_nn_onepass_fits": [I],
     "ndp_chamfer_l1_bwd": [V, I, V, I, F, V, V, V, V, V, V, I, V],
     "ndp_flow_metrics": [V, V, V, I, V, V],
     "ndp_landmark_mse_fwd_bwd": [V, V, I, V, V, V],
     "ndp_adam_step": [V, V, V, V, I, F, F, F, F, F, F, V],
     "ndp_engine_run": [ctypes.POINTER(Engine), I, I, V],
     "ndp_engine_run_timed": [ctypes.POINTER(Engine), I, I, V, c_float_p],
+    "ndp_engine_run_stages": [ctypes.POINTER(Engine), I, I, I, V],
     "ndp_engine_load": [ctypes.POINTER(Engine), I, ctypes.POINTER(LoadJob), I, V],
 }
 EXPORTS = ["ndp_version", "ndp_last_error", "ndp_build_id", "ndp_abi_sizes", "ndp_engine_nn_workspace"] + list(_SIGS)
@@ -176,7 +184,7 @@ def lib(allow_build=True):
                 build()
             if not os.path.exists(LIBPATH):
                 raise NdpError(f"{LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-            if _built_id(LIBPATH) != source_id():
+            if source_id() is not None and _built_id(LIBPATH) != source_id():
                 raise NdpError(f"{LIBPATH} was built from other sources (build id {_built_id(LIBPATH)}, tree {source_id()}): "
                                "run `python -c 'import __graft_entry__ as g; g.build()'`")
         L = ctypes.CDLL(override or LIBPATH)
@@ -213,43 +221,67 @@ class DrawOp(ctypes.Structure):
 HOST_SOURCES = [HOST_SOURCE, os.path.join(CSRC, "ndp_graph.cpp")]      # RNG replay; embedded-deformation graph builder
 
 
+HOST_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-mfma", "-mavx2", "-fPIC", "-shared"]
+
+
 def _host_id():
+    """Digest of the host library's sources and flags (compiled in as NDP_HOST_BUILD_ID), or None without sources."""
     import hashlib
     h = hashlib.sha256()
-    for src in HOST_SOURCES:
-        with open(src, "rb") as f:
-            h.update(f.read())
+    try:
+        for src in HOST_SOURCES:
+            with open(src, "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
+    h.update(" ".join(HOST_FLAGS).encode())
     return h.hexdigest()[:16]
 
 
+def _host_stale():
+    hid = _host_id()
+    built = _built_id(HOST_LIBPATH, b"NDP_HOST_ID")
+    if hid is None:
+        return built is None
+    return built != hid
+
+
 def build_host(force=False):
-    """g++ -> deformationpyramid_amd/lib/libndp_host.so; rebuilt when the digest of its sources changes (the digest sits
-    next to the library)."""
-    stamp = HOST_LIBPATH + ".id"
-    have = open(stamp).read().strip() if os.path.exists(stamp) else ""
-    if force or not os.path.exists(HOST_LIBPATH) or have != _host_id():
+    """g++ -> deformationpyramid_amd/lib/libndp_host.so; rebuilt when the digest of its sources changes (the digest is
+    compiled into the library).  Serialised by a file lock, staleness re-checked under the lock: N ranks build once."""
+    if force or _host_stale():
         import fcntl
         os.makedirs(LIBDIR, exist_ok=True)
         with open(os.path.join(LIBDIR, ".build_host.lock"), "w") as lock:
             fcntl.flock(lock, fcntl.LOCK_EX)
+            if not force and not _host_stale():
+                return HOST_LIBPATH
             tmp = f"{HOST_LIBPATH}.{os.getpid()}.tmp"
-            subprocess.check_call(["g++", "-O3", "-std=c++17", "-ffp-contract=off", "-mfma", "-fPIC", "-shared", "-o", tmp] + HOST_SOURCES)
+            subprocess.check_call(["g++"] + HOST_FLAGS + [f'-DNDP_HOST_BUILD_ID="{_host_id()}"', "-o", tmp] + HOST_SOURCES)
             os.replace(tmp, HOST_LIBPATH)
-            with open(stamp, "w") as f:
-                f.write(_host_id())
     return HOST_LIBPATH
 
 
 def host_lib():
     global _HOST
     if _HOST is None:
-        if shutil.which("g++"):
-            build_host()                                # no-op when the digest matches
+        if shutil.which("g++") and _host_id() is not None:
+            build_host()                                # no-op when the embedded digest matches
         if not os.path.exists(HOST_LIBPATH):
             raise NdpError(f"{HOST_LIBPATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        if _host_stale():                               # cannot be rebuilt here (no g++): refuse it, like the HIP library
+            raise NdpError(f"{HOST_LIBPATH} was built from other sources (build id {_built_id(HOST_LIBPATH, b'NDP_HOST_ID')}, "
+                           f"tree {_host_id()}): run `python -c 'import __graft_entry__ as g; g.build()'`")
         L = ctypes.CDLL(HOST_LIBPATH)
         L.ndp_rng_replay.argtypes = [V, ctypes.c_longlong, ctypes.POINTER(DrawOp), I, I, V, ctypes.c_longlong]
         L.ndp_rng_replay.restype = I
+        L.ndp_rng_skip.argtypes = [V, ctypes.c_longlong, ctypes.c_longlong]
+        L.ndp_rng_skip.restype = I
+        L.ndp_pair_draws.argtypes = [ctypes.POINTER(DrawOp), I, I, I]
+        L.ndp_pair_draws.restype = ctypes.c_longlong
+        L.ndp_pair_init.argtypes = [V, ctypes.c_longlong, ctypes.POINTER(DrawOp), I, V, I, I, I, V, V, V]
+        L.ndp_pair_init.restype = I
+        L.ndp_host_build_id.restype = ctypes.c_char_p
         L.ndp_depth_to_mesh.argtypes = [V, I, I, F, V, V, V, c_int_p, c_int_p]
         L.ndp_erode_mesh.argtypes = [I, V, I, I, I, V]
         L.ndp_sample_nodes.argtypes = [V, I, V, F, I, V]

@@ -20,13 +20,23 @@ namespace {
 constexpr int N = 624, M = 397;
 constexpr uint32_t MATRIX_A = 0x9908b0dfu, UMASK = 0x80000000u, LMASK = 0x7fffffffu;
 
+inline uint32_t temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+
+// at::mt19937 with torch's (left, next) bookkeeping: operator() is `if (--left == 0) regen(); return temper(s[next++]);`
+// -- with `left` = L on entry the next L - 1 calls read s[next ..] without a regeneration, the L-th regenerates first.
 struct Mt {
     uint32_t s[N];
     int left;
     uint32_t next;
     inline void regen() {
-        auto mix = [](uint32_t u, uint32_t v) { return (u & UMASK) | (v & LMASK); };
-        auto tw = [&](uint32_t u, uint32_t v) { return (mix(u, v) >> 1) ^ ((v & 1u) ? MATRIX_A : 0u); };
+        // branch-free twist; neither loop carries a dependency closer than 227 words, so both vectorise (-mavx2)
+        auto tw = [](uint32_t u, uint32_t v) { return (((u & UMASK) | (v & LMASK)) >> 1) ^ ((0u - (v & 1u)) & MATRIX_A); };
         int j = 0;
         for (; j < N - M; ++j) s[j] = s[j + M] ^ tw(s[j], s[j + 1]);
         for (; j < N - 1; ++j) s[j] = s[j + M - N] ^ tw(s[j], s[j + 1]);
@@ -36,23 +46,38 @@ struct Mt {
     }
     inline uint32_t raw() {              // at::mt19937::operator()
         if (--left == 0) regen();
-        uint32_t y = s[next++];
-        y ^= (y >> 11);
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= (y >> 18);
-        return y;
+        return temper(s[next++]);
     }
-    inline void discard(long long n) {   // advance without tempering
+    // n consecutive draws handed to f(pointer to untempered words, count) in bulk -- same stream as n calls of raw()
+    template <class F>
+    inline void bulk(long long n, F &&f) {
         while (n > 0) {
-            if (--left == 0) regen();
-            // after the decrement `left` more words (this one included) are available: left+... take them in bulk
-            long long avail = left;       // words still unread in this block, counting the current one
-            long long take = n < avail ? n : avail;
+            if (left == 1) {             // the next call regenerates, reads s[0] and leaves left = N
+                regen();
+                f(s, 1LL);
+                next = 1;
+                --n;
+                continue;
+            }
+            const long long take = n < (long long)(left - 1) ? n : (long long)(left - 1);
+            f(s + next, take);
             next += (uint32_t)take;
-            left -= (int)(take - 1);
+            left -= (int)take;
             n -= take;
         }
+    }
+    inline void discard(long long n) {   // advance without tempering
+        bulk(n, [](const uint32_t *, long long) {});
+    }
+    // n values ~ U(lo, lo + span) exactly as at::uniform_real_distribution<float> on torch's CPU generator
+    inline void uniform(float *dst, long long n, float lo, float span) {
+        bulk(n, [&](const uint32_t *w, long long k) {
+            for (long long i = 0; i < k; ++i) {
+                const float x = (float)(temper(w[i]) & ((1u << 24) - 1)) * (1.0f / 16777216.0f);
+                dst[i] = __builtin_fmaf(x, span, lo);      // ATen's AVX2/AVX512 kernels contract x*(to-from)+from
+            }
+            dst += k;
+        });
     }
 };
 
@@ -95,17 +120,77 @@ int ndp_rng_replay(unsigned char *rng_state, long long state_bytes, const ndp_dr
         for (int k = 0; k < n_ops; ++k) {
             const ndp_draw_op &op = ops[k];
             if (op.offset < 0) { g.discard(op.n); continue; }
-            float *dst = base + op.offset;
-            const float lo = op.lo, span = op.hi - op.lo;
-            for (long long i = 0; i < op.n; ++i) {
-                const float x = (float)(g.raw() & ((1u << 24) - 1)) * (1.0f / 16777216.0f);
-                dst[i] = __builtin_fmaf(x, span, lo);      // ATen's AVX2/AVX512 kernels contract x*(to-from)+from
-            }
+            g.uniform(base + op.offset, op.n, op.lo, op.hi - op.lo);
         }
     }
     export_state(g, rng_state);
     return 0;
 }
 
-int ndp_host_version(void) { return 100; }
+// ---- multi-threaded pair producer (registration.py:133-159 for MANY pairs) ---------------------------------------
+// The per-pair draw counts are known up front (the init ops + the two randperm calls), so ONE thread can walk the
+// generator from pair to pair (ndp_rng_skip: regenerations only, no tempering / float transform) and hand every pair
+// the generator state it starts from; any number of workers then replay their pair from that snapshot
+// (ndp_pair_init) -- bit-identical to the sequential order of Registration.register() calls.
+
+// advance the generator state blob by n raw draws
+int ndp_rng_skip(unsigned char *rng_state, long long state_bytes, long long n) {
+    if (!rng_state || state_bytes < 24 + 8 * N || n < 0) return -1;
+    Mt g;
+    import_state(rng_state, g);
+    g.discard(n);
+    export_state(g, rng_state);
+    return 0;
+}
+
+// first `keep` entries of torch.randperm(n) on the CPU generator (randperm_cpu, n < 2^32 / 20: r = arange(n); for i < n - 1:
+// swap(r[i], r[i + random() % (n - i)]) -- entry i is final after step i); always consumes n - 1 draws.  scratch: n ints.
+static void randperm_prefix(Mt &g, int n, int keep, int *scratch, int *out) {
+    if (n <= 0) return;
+    for (int i = 0; i < n; ++i) scratch[i] = i;
+    const int steps = keep < n - 1 ? keep : n - 1;
+    for (int i = 0; i < steps; ++i) {
+        const int z = (int)(g.raw() % (uint32_t)(n - i));
+        const int a = scratch[i];
+        scratch[i] = scratch[z + i];
+        scratch[z + i] = a;
+    }
+    g.discard((long long)(n - 1) - steps);
+    const int k = keep < n ? keep : n;
+    for (int i = 0; i < k; ++i) out[i] = scratch[i];
+}
+
+// raw draws one pair consumes: the init ops + randperm(n_src) + randperm(n_tgt)
+long long ndp_pair_draws(const ndp_draw_op *ops, int n_ops, int n_src, int n_tgt) {
+    long long tot = 0;
+    for (int k = 0; k < n_ops; ++k) tot += ops[k].n;
+    return tot + (n_src > 1 ? n_src - 1 : 0) + (n_tgt > 1 ? n_tgt - 1 : 0);
+}
+
+// One pair from a state SNAPSHOT (read only): the pyramid initialisation into `out` (draw ops as ndp_rng_replay) and the first
+// `samples` entries of the two sampling permutations (registration.py:156-159) into perm_s / perm_t (int32).
+// scratch: max(n_src, n_tgt) ints.  Thread safe (no shared state).
+int ndp_pair_init(const unsigned char *rng_state, long long state_bytes, const ndp_draw_op *ops, int n_ops, float *out,
+                  int n_src, int n_tgt, int samples, int *perm_s, int *perm_t, int *scratch) {
+    if (!rng_state || state_bytes < 24 + 8 * N || !ops || n_ops < 0 || !out || n_src < 1 || n_tgt < 1 || samples < 0 || !perm_s ||
+        !perm_t || !scratch)
+        return -1;
+    Mt g;
+    import_state(rng_state, g);
+    for (int k = 0; k < n_ops; ++k) {
+        const ndp_draw_op &op = ops[k];
+        if (op.offset < 0) g.discard(op.n);
+        else g.uniform(out + op.offset, op.n, op.lo, op.hi - op.lo);
+    }
+    randperm_prefix(g, n_src, samples, scratch, perm_s);
+    randperm_prefix(g, n_tgt, samples, scratch, perm_t);
+    return 0;
+}
+
+#ifndef NDP_HOST_BUILD_ID
+#define NDP_HOST_BUILD_ID "unknown"
+#endif
+static const char k_host_tag[] = "NDP_HOST_ID=" NDP_HOST_BUILD_ID;       // the loader finds this tag in the file without loading it
+const char *ndp_host_build_id(void) { return k_host_tag + 12; }
+int ndp_host_version(void) { return 110; }
 }

@@ -2386,20 +2386,26 @@ extern "C" int ndp_adam_step(float *params, const float *grads, float *m, float 
 }
 
 // one tick = NDP_TICK_KERNELS launches; ev (optional): NDP_TICK_KERNELS + 1 events per tick recorded around them
-static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipStream_t s, hipEvent_t *ev) {
+// stages [stage_lo, stage_hi] of every tick: 0 forward, 1 nearest neighbours, 2 loss / decision / dL/dx', 3 bwd2, 4 bwd1, 5 update
+static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipStream_t s, hipEvent_t *ev, int stage_lo = 0, int stage_hi = NDP_TICK_KERNELS - 1) {
     if (int rc = check_engine(e, "ndp_engine_run")) return rc;
     const bool nn = e->w_cd != 0.f && e->t_cap > 0;
     if (nn && (!e->nn_row || !e->d2x || !e->d2y || !e->idx_x || !e->idx_y || !e->tgt))
         return fail(NDP_E_INVALID, "ndp_engine_run: Chamfer term without nearest-neighbour buffers");
+    if (nn && (e->nn_mode < 0 || e->nn_mode > 2))
+        return fail(NDP_E_INVALID, "ndp_engine_run: nn_mode must be 0 (one pass, vector pipe), 1 (latency shape) or 2 (one pass, matrix pipe)");
+    // the column table of the one-pass vector kernel lives in LDS: only that shape has a size limit (the latency shape and
+    // landmark-only engines never launch k_eng_nn)
     const int stage_x = nn1_stage_x(e->n_cap) ? 1 : 0;
     const int nn_lds = nn1_lds_floats(e->n_cap, stage_x) * 4;
-    if (nn_lds > 160 * 1024) return fail(NDP_E_UNSUPPORTED, "ndp_engine_run: n_cap too large for the one-pass nearest-neighbour kernel");
+    if (nn && e->nn_mode == 0) {
+        if (nn_lds > 160 * 1024)
+            return fail(NDP_E_UNSUPPORTED, "ndp_engine_run: n_cap too large for the one-pass nearest-neighbour kernel (nn_mode 0); use nn_mode 1");
+        if (int rc = set_smem((const void *)k_eng_nn, nn_lds)) return rc;
+    }
     if (int rc = set_smem((const void *)k_eng_fwd, kSmemFwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
-    if (nn) if (int rc = set_smem((const void *)k_eng_nn, nn_lds)) return rc;
-    if (nn && (e->nn_mode < 0 || e->nn_mode > 2))
-        return fail(NDP_E_INVALID, "ndp_engine_run: nn_mode must be 0 (one pass, vector pipe), 1 (latency shape) or 2 (one pass, matrix pipe)");
     if (nn && e->nn_mode == 2) {
         if (!nn2_fits(e->n_cap)) return fail(NDP_E_UNSUPPORTED, "ndp_engine_run: n_cap too large for nn_mode 2 (sources + column table must fit LDS)");
         if (int rc = set_smem((const void *)k_eng_nn_mx, nn2_lds_floats(e->n_cap) * 4)) return rc;
@@ -2422,25 +2428,33 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         hipEvent_t *q = ev ? ev + (size_t)k * (NDP_TICK_KERNELS + 1) : nullptr;
         int j = 0;
 #define NDP_EV() do { if (q) (void)hipEventRecord(q[j++], s); } while (0)
+#define NDP_ST(i) ((i) >= stage_lo && (i) <= stage_hi)
         NDP_EV();
-        if (e->gemm_mode & 1) {
+        if (!NDP_ST(0)) {}
+        else if (e->gemm_mode & 1) {
             hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity);
             hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
         }
         else hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         NDP_EV();
-        if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);
+        if (!NDP_ST(1)) {}
+        else if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);
         else if (nn && e->nn_mode == 2) hipLaunchKernelGGL(k_eng_nn_mx, g_nn, blk, nn2_lds_floats(e->n_cap) * 4, s, *e, parity);
         else if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, nn_lds, s, *e, parity, stage_x);
-        NDP_EV(); hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         NDP_EV();
-        if (e->gemm_mode & 4) hipLaunchKernelGGL(k_eng_bwd2_8, g_fwd8, dim3(512), kSmemBwd8Bytes, s, *e, parity);
+        if (NDP_ST(2)) hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
+        NDP_EV();
+        if (!NDP_ST(3)) {}
+        else if (e->gemm_mode & 4) hipLaunchKernelGGL(k_eng_bwd2_8, g_fwd8, dim3(512), kSmemBwd8Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV();
-        if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd18Bytes, s, *e, parity);
+        if (!NDP_ST(4)) {}
+        else if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd18Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
-        NDP_EV(); hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
         NDP_EV();
+        if (NDP_ST(5)) hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        NDP_EV();
+#undef NDP_ST
 #undef NDP_EV
     }
     HIP_TRY(hipGetLastError(), "engine launch");
@@ -2485,9 +2499,18 @@ extern "C" int ndp_chamfer_nn_matrix(const float *x, int S, const float *y, int 
     return 0;
 }
 extern "C" int ndp_engine_nn_matrix_fits(int n_cap) { return nn2_fits(n_cap) ? 1 : 0; }
+extern "C" int ndp_engine_nn_onepass_fits(int n_cap) { return nn1_lds_floats(n_cap, nn1_stage_x(n_cap)) * 4 <= 160 * 1024 ? 1 : 0; }
 
 extern "C" int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream) {
     return engine_launch_ticks(e, tick0, n_ticks, (hipStream_t)stream, nullptr);
+}
+
+// ONE tick, only the launches of stages [stage_lo, stage_hi] (0 forward, 1 nearest neighbours, 2 loss / decision / dL/dx', 3 bwd2,
+// 4 bwd1, 5 update): a test and measurement aid -- the buffers each kernel leaves behind (activations, dO, dz1, gradient partials)
+// can be inspected between the stages.  Running the stages 0..5 of a tick in order, in any grouping, is ndp_engine_run(e, tick, 1).
+extern "C" int ndp_engine_run_stages(const ndp_engine *e, int tick, int stage_lo, int stage_hi, void *stream) {
+    if (stage_lo < 0 || stage_hi >= NDP_TICK_KERNELS || stage_lo > stage_hi) return fail(NDP_E_INVALID, "ndp_engine_run_stages: stages are 0..5, lo <= hi");
+    return engine_launch_ticks(e, tick, 1, (hipStream_t)stream, nullptr, stage_lo, stage_hi);
 }
 
 // Profiling variant of ndp_engine_run: HIP events around every kernel of every tick, recorded on the launch stream;

@@ -8,8 +8,10 @@ The deformation graph comes from the native builder (geometry.py -> csrc/ndp_gra
 MVRegC); the loop is host driven, exactly like upstream: every iteration draws fresh Chamfer samples with two CPU randperms,
 so there is nothing to keep resident -- it is a comparison baseline, not the hot path.  Warp, ARAP, Chamfer, the node
 gradients and Adam run in libndp_hip.so (`ndp_ed_warp`, `ndp_ed_arap`, `ndp_ed_grad`, the NDP Chamfer / Adam operators).
-Two upstream quirks are kept: -1 anchor / edge slots index the last node with weight 0, and `loss_prev` is never updated
-inside the loop (registration.py:428-433), so only `loss < 1e-5` or the iteration cap end it.  No CPU fallback.
+Three upstream quirks are kept: -1 anchor / edge slots index the last node with weight 0; `loss_prev` is never updated
+inside the loop (registration.py:428-433), so only `loss < 1e-5` or the iteration cap end it; and the final full-cloud warp
+uses the rotations computed at the top of the last iteration (one Adam step behind phi) with the updated translations
+(registration.py:376, 449-453).  No CPU fallback.
 """
 import ctypes
 
@@ -74,10 +76,11 @@ class EDGraph:
         self.R = torch.empty(self.n, 9, device=self.dev, dtype=torch.float32)
         self.reg = torch.empty(1, device=self.dev, dtype=torch.float32)
 
-    def warp(self, params, x, anchors, weights):
-        """params: flat [phi (3n) | t (3n)]; x [S,3]; anchors [S,6] int32; weights [S,6]."""
+    def warp(self, params, x, anchors, weights, keep_R=False):
+        """params: flat [phi (3n) | t (3n)]; x [S,3]; anchors [S,6] int32; weights [S,6].  keep_R: do not recompute the node
+        rotations from phi -- warp with the R of the previous call and the CURRENT translations."""
         y = torch.empty_like(x)
-        N.check(N.lib().ndp_ed_warp(_p(x), x.shape[0], _p(anchors), _p(weights), _p(self.nodes), self.n, _p(params),
+        N.check(N.lib().ndp_ed_warp(_p(x), x.shape[0], _p(anchors), _p(weights), _p(self.nodes), self.n, None if keep_R else _p(params),
                                     _p(params[3 * self.n:]), _p(self.R), _p(y), N.stream_ptr(self.dev)), "ndp_ed_warp")
         return y
 
@@ -142,7 +145,9 @@ def optimize_Embeded_deformation(reg, visualize=False):
         ops.adam_step(params, grads, m, v, steps, lr=lr)
         lr = lr * 0.999                                                            # ExponentialLR(gamma=0.999).step()   (:367, :445)
     reg.last_ed = dict(iters=steps, trace=trace)
-    warped_pcd = graph.warp(params, reg.src_pcd_raw, anchors_all, weights_all)     # :449-453
+    # :449-453 -- upstream warps with the R computed at the top of the LAST loop iteration (:376), i.e. one Adam step behind phi,
+    # together with the updated translations; kept (the loop's last warp() left exactly that R in graph.R)
+    warped_pcd = graph.warp(params, reg.src_pcd_raw, anchors_all, weights_all, keep_R=len(trace) > 0)
     s_uv = pc_2_uv(reg.src_pcd, reg.intrinsics)                                    # :459-464: motion of the dataset's sampled cloud
     pix_map = reg.src_pix_2_pcd_map[-1].to(dev)
     s_id = pix_map[s_uv[:, 1], s_uv[:, 0]]

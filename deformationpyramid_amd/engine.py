@@ -35,19 +35,62 @@ class OptConfig:
     early_stop: bool = True
 
 
+# Arithmetic of the three level kernels / shape of the nearest-neighbour kernel when the caller does not say (ctor argument >
+# environment NDP_GEMM_MODE / NDP_NN_MODE > these defaults):
+#   gemm_mode 0: 128x128 contractions on the fp32 MFMA, bitwise the oracle's fma chain;
+#             7: (mask 1 forward | 2 bwd1 | 4 bwd2) the same contractions as three-way bf16 splits on the bf16 MFMA with fp32
+#                accumulation -- fp32-level accuracy (tests/test_split_accuracy.py), not bitwise the chain;
+#   nn matrix : the one-pass NN with the distances on the bf16 matrix pipe and exact re-evaluation (bit-identical results).
+DEFAULT_GEMM_MODE = 0
+DEFAULT_NN_MATRIX = False
+
+
+def resolve_modes(B, n_cap, t_cap, gemm_mode=None, nn_mode=None, nn_matrix=None):
+    """-> (gemm_mode, nn_mode) an engine of B slots x (n_cap, t_cap) will run with, validated against the LDS limits of the
+    one-pass kernels.  An explicit nn_mode that does not fit raises; a default / environment choice degrades (2 -> 0 -> 1).
+    nn_matrix (None: DEFAULT_NN_MATRIX) only states a preference for the throughput shape: matrix-pipe kernel where it fits."""
+    lib = N.lib()
+    if gemm_mode is None:
+        gemm_mode = int(os.environ.get("NDP_GEMM_MODE", DEFAULT_GEMM_MODE))
+    gemm_mode = int(gemm_mode)
+    if not 0 <= gemm_mode <= 7:
+        raise N.NdpError(f"gemm_mode must be a mask of 1 (forward) | 2 (bwd1) | 4 (bwd2), got {gemm_mode}")
+    fits2 = bool(lib.ndp_engine_nn_matrix_fits(n_cap))
+    fits0 = bool(lib.ndp_engine_nn_onepass_fits(n_cap))
+    if nn_mode is not None:
+        nn_mode = int(nn_mode)
+        if nn_mode not in (0, 1, 2):
+            raise N.NdpError(f"nn_mode must be 0 (one pass, vector pipe), 1 (latency shape) or 2 (one pass, matrix pipe), got {nn_mode}")
+        if (nn_mode == 2 and not fits2) or (nn_mode == 0 and not fits0):
+            raise N.NdpError(f"nn_mode {nn_mode}: n_cap = {n_cap} sources do not fit the kernel's LDS table "
+                             "(ndp_engine_nn_matrix_fits / ndp_engine_nn_onepass_fits); use nn_mode 1 or leave the choice to the engine")
+        return gemm_mode, nn_mode
+    env = os.environ.get("NDP_NN_MODE")
+    if env:                                          # experiments (tools/tick_bench.py): force a shape where it fits
+        want = int(env)
+    elif B * (t_cap // 256 + 1) < 256:               # few resident pairs: the one-pass kernels have only t_cap/256 workgroups per
+        want = 1                                     # pair, the latency shape has (n_cap + t_cap)/64
+    else:
+        want = 2 if (DEFAULT_NN_MATRIX if nn_matrix is None else nn_matrix) else 0
+    if want == 2 and not fits2:
+        want = 0
+    if want == 0 and not fits0:
+        want = 1
+    return gemm_mode, want
+
+
 class BatchedEngine:
-    def __init__(self, desc: LayerDesc, cfg: OptConfig, B: int, n_cap: int, t_cap: int, device, G=None, nn_mode=None, gemm_mode=None):
+    def __init__(self, desc: LayerDesc, cfg: OptConfig, B: int, n_cap: int, t_cap: int, device, G=None, nn_mode=None, gemm_mode=None, nn_matrix=None):
         # desc.nonrigidity = True means "every level but the first carries the gate" (nets.py:26); P is then the
         # parameter count of a gated level and level 0 uses a prefix-compatible shorter layout.
         self.lib = N.lib()
         self.desc, self.cfg, self.B = desc, cfg, B
-        # 0: level forward on the fp32 MFMA (bitwise the oracle's chain, default); 1: opt-in, bf16-split layers (csrc/ndp_fwd_bf16.inc)
-        self.gemm_mode = int(gemm_mode) if gemm_mode is not None else int(os.environ.get("NDP_GEMM_MODE", "0"))
-        self.nn_mode = nn_mode                     # None: chosen from B and n_cap (see _mk_struct); 0 one-pass, 1 latency shape
+        self.n_cap, self.t_cap = cap(n_cap), cap(t_cap)
+        # modes are resolved and validated HERE, once (see resolve_modes): nothing later reads the environment
+        self.gemm_mode, self.nn_mode = resolve_modes(B, self.n_cap, self.t_cap, gemm_mode, nn_mode, nn_matrix)
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise N.NdpError("BatchedEngine needs a GPU device; there is no CPU fallback")
-        self.n_cap, self.t_cap = cap(n_cap), cap(t_cap)
         self.P = desc.param_count
         self.p_stride = (self.P + 63) // 64 * 64
         tiles = self.n_cap // N.TILE
@@ -100,15 +143,7 @@ class BatchedEngine:
         e.w_cd, e.trunc = c.w_cd, c.trunc
         e.w_reg = c.w_reg if self.desc.nonrigidity else 0.0
         e.adam_w1, e.adam_b2, e.adam_w2, e.adam_eps = 1 - 0.9, 0.999, 1 - 0.999, 1e-8
-        # few resident pairs: the one-pass kernel has only t_cap/256 workgroups per pair; the latency shape has (n_cap + t_cap)/64
-        if self.nn_mode is None and os.environ.get("NDP_NN_MODE"):            # experiments (tools/tick_bench.py): force a shape
-            self.nn_mode = int(os.environ["NDP_NN_MODE"])
-            if self.nn_mode == 2 and not N.lib().ndp_engine_nn_matrix_fits(self.n_cap):
-                self.nn_mode = 0                                                  # sources + column table do not fit LDS: vector kernel
-        if self.nn_mode is not None:
-            e.nn_mode = int(self.nn_mode)
-        else:
-            e.nn_mode = 1 if self.B * (self.t_cap // 256 + 1) < 256 else 0
+        e.nn_mode = self.nn_mode
         for name in ("geom", "state", "pts", "ldmk_t", "tgt", "params", "gpart", "adam_m", "adam_v", "act", "heads",
                      "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "dO", "nn_row"):
             setattr(e, name, getattr(self, name).data_ptr())
@@ -174,6 +209,14 @@ class BatchedEngine:
                                         N.stream_ptr(self.device)), "ndp_engine_run")
         self.tick += n_ticks
 
+    def run_stages(self, lo, hi):
+        """Stages lo..hi (0 forward, 1 NN, 2 loss, 3 bwd2, 4 bwd1, 5 update) of the CURRENT tick; the tick counter advances
+        once stage 5 has run.  Test / measurement aid (ndp_engine_run_stages)."""
+        N.check(self.lib.ndp_engine_run_stages(ctypes.byref(self.c_engine), self.tick, int(lo), int(hi),
+                                               N.stream_ptr(self.device)), "ndp_engine_run_stages")
+        if hi == len(N.TICK_KERNELS) - 1:
+            self.tick += 1
+
     def run_ticks_timed(self, n_ticks):
         """-> per-kernel summed milliseconds, in N.TICK_KERNELS order (HIP events on the launch stream)."""
         ms = (ctypes.c_float * len(N.TICK_KERNELS))()
@@ -206,12 +249,18 @@ class BatchedEngine:
         sz = self.state_nbytes
         return [N.PairState.from_buffer_copy(raw[i * sz:(i + 1) * sz]) for i in range(self.B)]
 
-    def run_until_done(self, chunk=32, max_ticks=None):
-        """Advance every loaded slot to the end of its last level; returns the slot states."""
+    def run_until_done(self, chunk=32, max_ticks=None, kernel_ms=None):
+        """Advance every loaded slot to the end of its last level; returns the slot states.  kernel_ms (a list of
+        len(N.TICK_KERNELS) floats, optional) accumulates the per-kernel device milliseconds of the ticks (HIP events on the
+        launch stream, ndp_engine_run_timed) -- what register(timer=...) apportions to the reference's timer keys."""
         limit = max_ticks if max_ticks is not None else self.cfg.m * (self.cfg.iters + 1) + chunk
         done_ticks = 0
         while True:
-            self.run_ticks(chunk)
+            if kernel_ms is None:
+                self.run_ticks(chunk)
+            else:
+                for j, v in enumerate(self.run_ticks_timed(chunk)):
+                    kernel_ms[j] += v
             done_ticks += chunk
             st = self.read_states()
             if all(s.level >= self.cfg.m for s in st) or done_ticks >= limit:

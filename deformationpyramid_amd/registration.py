@@ -15,6 +15,7 @@ Host work stays in torch (tensor plumbing, the CPU RNG replay of the reference's
 randperm calls); the optimisation itself runs in libndp_hip.so.  There is no CPU fallback:
 config.device must be a GPU.
 """
+import ctypes
 import gc
 import queue
 import threading
@@ -27,7 +28,7 @@ from . import _native as N
 from . import ops
 from .engine import BatchedEngine, OptConfig
 from .layout import LayerDesc
-from .nets import init_pyramid_store
+from .nets import _draw_ops, _native_rng_ok, init_pyramid_store
 
 
 class _Prepared:
@@ -50,6 +51,37 @@ class _Prepared:
         """Drop the device staging once the final warp has been enqueued (the allocator keeps the memory alive for
         the streams the tensors were recorded on)."""
         self.buf = self.store = self.perm_s = self.perm_t = self.tgt_pcd = self.ldmk_s = self.ldmk_t = None
+
+
+class _PinRing:
+    """Pinned float32 staging buffers of ONE preparing thread, reused once their upload has completed (allocated once:
+    hipHostMalloc costs milliseconds), plus that thread's integer scratch for the permutation replay."""
+
+    def __init__(self):
+        self.free, self.busy, self._scratch = [], [], None
+
+    def take(self, numel):
+        while self.busy and self.busy[0][1].query():
+            self.free.append(self.busy.pop(0)[0])
+        for i, buf in enumerate(self.free):
+            if buf.numel() == numel:
+                return self.free.pop(i)
+        if len(self.busy) >= 64:                                                    # bound the ring: wait for the oldest
+            host, ev = self.busy.pop(0)
+            ev.synchronize()
+            if host.numel() == numel:
+                return host
+        return torch.empty(numel, dtype=torch.float32).pin_memory()
+
+    def uploaded(self, host, stream):
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        self.busy.append((host, ev))
+
+    def scratch(self, n):
+        if self._scratch is None or self._scratch.numel() < n:
+            self._scratch = torch.empty(max(n, 8192), dtype=torch.int32)
+        return self._scratch
 
 
 class _BatchCtx:
@@ -144,7 +176,12 @@ class _Lane:
 
 
 class Registration:
-    def __init__(self, config):
+    def __init__(self, config, gemm_mode=None, nn_mode=None, nn_matrix=None):
+        """config: the reference's attribute-accessible config (NDP.yaml / LNDP.yaml keys).  gemm_mode / nn_mode (extension, both
+        default to the engine's choice, see engine.resolve_modes): arithmetic of the level kernels' 128x128 contractions (0: fp32
+        MFMA, bitwise the oracle's chain; 7: three-way bf16 splits on the bf16 MFMA), a forced shape of the nearest-neighbour kernel
+        (nn_mode) or just the preference for its matrix-pipe variant where the engine picks the throughput shape (nn_matrix)."""
+        self.gemm_mode, self.nn_mode, self.nn_matrix = gemm_mode, nn_mode, nn_matrix
         self.tgt_pcd = None
         self.src_pcd = None
         self.landmarks = None
@@ -189,26 +226,43 @@ class Registration:
     def optimize_deformation_pyramid(self, visualize=False, timer=None):
         if visualize:
             raise NotImplementedError("mayavi visualisation is outside the hot path")
-        t0 = time.time()
         prep = self._prepare(self.src_pcd, self.tgt_pcd, self.landmarks)
         self.src_pcd = prep.src_pcd
         eng = self._engine(1, prep)
         eng.load_jobs([prep.load_job(0)])
-        st = eng.run_until_done(chunk=32)[0]
+        kernel_ms = [0.0] * len(N.TICK_KERNELS) if timer is not None else None
+        st = eng.run_until_done(chunk=32, kernel_ms=kernel_ms)[0]
         warped = self._finish(eng, [(0, prep)])[0]
         self.last_state = st
         iter_cnt = {lvl: int(st.evals_per_level[lvl]) for lvl in range(self.config.m)}
         if timer is not None:
-            torch.cuda.synchronize(self._dev())
-            timer.tictoc("ndp_engine", time.time() - t0)
+            self._fill_timer(timer, kernel_ms, st, prep.K > 0)
         return warped, iter_cnt, timer
 
+    @staticmethod
+    def _fill_timer(timer, kernel_ms, st, has_ldmk):
+        """The reference tics `lvl_warp` and `Chamfer` once per loss evaluation (only without landmarks) and `backprop` once per
+        Adam step (registration.py:207-213, 234-238), and eval_nolearned.py:139-146 prints those keys.  The iteration never
+        returns to the host here, so the pair's DEVICE time per kernel (HIP events around every launch, ndp_engine_run_timed) is
+        apportioned: lvl_warp = level forward, Chamfer = nearest neighbours + loss / early-stop decision / dL/dx', backprop =
+        the two backward kernels + gradient fold and Adam -- recorded as one tictoc per evaluation / step, so that `calls` and
+        `average` mean what they mean upstream."""
+        ms = dict(zip(N.TICK_KERNELS, kernel_ms))
+        groups = [("backprop", (ms["k_eng_bwd2"] + ms["k_eng_bwd1"] + ms["k_eng_update"]) * 1e-3, int(st.total_steps))]
+        if not has_ldmk:
+            groups = [("lvl_warp", ms["k_eng_fwd"] * 1e-3, int(st.total_evals)),
+                      ("Chamfer", (ms["k_eng_nn"] + ms["k_eng_loss"]) * 1e-3, int(st.total_evals))] + groups
+        for key, total, calls in groups:
+            for _ in range(calls):
+                timer.tictoc(key, total / calls)
+
     # ------------------------------------------------------------------ batched extension
-    def register_batch(self, pairs, slots=64, chunk=8, prefetch=True, engines=1):
+    def register_batch(self, pairs, slots=64, chunk=8, prefetch=True, engines=1, workers=3):
         """pairs: sequence of (src, tgt) or (src, tgt, (ldmk_s, ldmk_t)).  Pairs are prepared in order
         (so the CPU RNG stream is consumed exactly as by sequential register() calls) and optimised
         `slots` at a time per engine, finished slots being refilled.  With prefetch=True the host-side preparation
-        (RNG replay of the init and of the sampling permutations) runs in a producer thread ahead of the GPU.
+        (RNG replay of the init and of the sampling permutations) runs ahead of the GPU in `workers` producer threads fed by
+        one generator-stepping thread (see below: bit-identical to the sequential order whatever the thread count).
         engines > 1 keeps that many independent engines ticking on their own HIP streams: their launches interleave on
         the GPU, so the VALU-bound and latency-bound kernels of one overlap the MFMA-bound kernels of another.
         Returns [(warped, iter_cnt)] in input order."""
@@ -223,79 +277,135 @@ class Registration:
                              "(registration.py:189-212); register them in separate batches")
         k_max = max(ks)
         engines = max(1, min(int(engines), len(pairs)))
-        todo = queue.Queue(maxsize=max(2 * slots * engines, 8))
         preps = [None] * len(pairs)
         dev = self._dev()
-        # the streams live as long as the Registration: the caching allocator pools memory per stream, and fresh
-        # streams on every call made its reserved memory grow by ~0.7 GB per 512 pairs
-        side = self._stream("side", dev) if prefetch else None
         fin_stream = self._stream("fin", dev)                    # final all-point warps overlap the ticking engines
-
+        # Host-side preparation (the RNG replay of the reference's init and of its two randperm calls, registration.py:133-159)
+        # runs ahead of the GPU.  The draw counts per pair are known up front, so ONE stepper thread walks torch's CPU generator
+        # from pair to pair (regenerations only) and hands each pair the generator state it starts from; `workers` threads replay
+        # their pairs from those snapshots natively (GIL released) on their own side streams -- bit-identical to sequential
+        # register() calls, in any completion order.  Pair i is prepared by worker i % W and delivered in index order.
+        W = max(1, int(workers)) if prefetch else 0
+        native = prefetch and _native_rng_ok()
+        if not native:
+            W = min(W, 1)                                        # the torch-call replay consumes the global generator: one thread
+        depth_q = max(2 * slots * engines // max(W, 1), 4)
+        out_q = [queue.Queue(maxsize=depth_q) for _ in range(max(W, 1))]
+        in_q = [queue.Queue(maxsize=8) for _ in range(W)] if native else []
         stop = threading.Event()
 
-        def put(item):
-            """Bounded put that gives up when the consumer has failed (so the thread never stays blocked)."""
+        def put(q, item):
+            """Bounded put that gives up when the consumer has failed (so a thread never stays blocked)."""
             while not stop.is_set():
                 try:
-                    todo.put(item, timeout=0.1)
+                    q.put(item, timeout=0.1)
                     return True
                 except queue.Full:
                     pass
             return False
 
-        def produce():
+        def as_tensors(item):
+            src, tgt = item[0], item[1]
+            ldmk = item[2] if len(item) > 2 else None
+            if isinstance(src, np.ndarray):
+                src, tgt = torch.from_numpy(src), torch.from_numpy(tgt)
+            return src, tgt, ldmk
+
+        def prepare_on(side, ring, item, rng_state):
+            src, tgt, ldmk = as_tensors(item)
+            with torch.cuda.stream(side):
+                p = self._prepare(src.to(dev), tgt.to(dev), ldmk, rng_state=rng_state, ring=ring)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            return p, ev
+
+        def stepper():
+            """Walks the generator over all pairs; pair i starts from the snapshot taken before its draws."""
             try:
+                L = N.host_lib()
+                st = torch.get_rng_state()
                 for i, item in enumerate(pairs):
                     if stop.is_set():
                         return
-                    src, tgt = item[0], item[1]
-                    ldmk = item[2] if len(item) > 2 else None
-                    if isinstance(src, np.ndarray):
-                        src, tgt = torch.from_numpy(src), torch.from_numpy(tgt)
-                    if side is not None:
-                        with torch.cuda.stream(side):
-                            p = self._prepare(src.to(dev), tgt.to(dev), ldmk)
-                            ev = torch.cuda.Event()
-                            ev.record(side)
-                    else:
-                        p, ev = self._prepare(src.to(dev), tgt.to(dev), ldmk), None
-                    if not put((i, p, ev)):
+                    n_src, n_tgt = int(item[0].shape[0]), int(item[1].shape[0])
+                    if not put(in_q[i % W], (i, item, st.clone())):
                         return
-                put(None)
-            except BaseException as e:       # surface producer failures in the consumer
-                put(e)
+                    if L.ndp_rng_skip(ctypes.c_void_p(st.data_ptr()), st.numel(), self._pair_draws(n_src, n_tgt)) != 0:
+                        raise N.NdpError("ndp_rng_skip failed")
+                torch.set_rng_state(st)                           # where sequential register() calls would have left it
+                for q in in_q:
+                    put(q, None)
+            except BaseException as e:                            # surface the failure in the consumer
+                for q in out_q:
+                    put(q, e)
 
-        th = None
-        if prefetch:
-            th = threading.Thread(target=produce, daemon=True)
+        def worker(w):
+            try:
+                side, ring = self._stream(("side", w), dev), self._pin_ring(w)
+                while not stop.is_set():
+                    try:
+                        task = in_q[w].get(timeout=0.1)
+                    except queue.Empty:
+                        continue
+                    if task is None:
+                        put(out_q[w], None)
+                        return
+                    i, item, st = task
+                    p, ev = prepare_on(side, ring, item, st)
+                    if not put(out_q[w], (i, p, ev)):
+                        return
+            except BaseException as e:
+                put(out_q[w], e)
+
+        def produce_sequential():
+            """One thread on the global generator (no native replay available)."""
+            try:
+                side, ring = self._stream(("side", 0), dev), self._pin_ring(0)
+                for i, item in enumerate(pairs):
+                    if stop.is_set():
+                        return
+                    p, ev = prepare_on(side, ring, item, None)
+                    if not put(out_q[0], (i, p, ev)):
+                        return
+                put(out_q[0], None)
+            except BaseException as e:
+                put(out_q[0], e)
+
+        threads = []
+        if native:
+            threads = [threading.Thread(target=stepper, daemon=True)] + [threading.Thread(target=worker, args=(w,), daemon=True) for w in range(W)]
+        elif prefetch:
+            threads = [threading.Thread(target=produce_sequential, daemon=True)]
+        for th in threads:
             th.start()
-        else:
-            # unbounded in-line preparation
-            todo = queue.Queue()
-            produce()
+        cursor = [0]                                             # index of the next pair to hand out
 
         def next_prepared(stream, block=True):
-            """Next pair off the producer queue, made visible to `stream` (a lane's stream) and to fin_stream.
-            block=False: _NOT_READY when the producer has nothing queued yet."""
-            try:
-                item = todo.get(block=block)
-            except queue.Empty:
-                return _NOT_READY
+            """Next pair (in index order) made visible to `stream` (a lane's stream) and to fin_stream.
+            block=False: _NOT_READY when its worker has not finished it yet."""
+            i = cursor[0]
+            if i >= len(pairs):
+                return None
+            if not prefetch:                                     # in-line preparation on the caller's stream
+                src, tgt, ldmk = as_tensors(pairs[i])
+                item = (i, self._prepare(src.to(dev), tgt.to(dev), ldmk), None)
+            else:
+                try:
+                    item = out_q[i % max(W, 1)].get(block=block)
+                except queue.Empty:
+                    return _NOT_READY
             if item is None:
                 return None
             if isinstance(item, BaseException):
                 raise item
             i, p, ev = item
+            cursor[0] = i + 1
             if ev is not None:
                 stream.wait_event(ev)
                 fin_stream.wait_event(ev)
-                for t in p.tensors():                # allocated on the producer's stream, consumed on these two
-                    t.record_stream(stream)
-                    t.record_stream(fin_stream)
-            else:
-                for t in p.tensors():
-                    t.record_stream(stream)
-                    t.record_stream(fin_stream)
+            for t in p.tensors():                                # allocated on the producer's stream, consumed on these two
+                t.record_stream(stream)
+                t.record_stream(fin_stream)
             preps[i] = p
             return i, p
 
@@ -303,10 +413,12 @@ class Registration:
         main = torch.cuda.current_stream(dev)
         ctx = _BatchCtx(self, preps, next_prepared, fin_stream, main, chunk, m)
 
-        # the cyclic collector's full passes over thousands of live pair objects stalled every lane for 50-85 ms a few times per
-        # batch (rocprofv3 trace of the bench); nothing in the loop builds reference cycles worth collecting before it ends
-        gc_was_on = gc.isenabled()
-        gc.disable()
+        # the cyclic collector's FULL passes over thousands of live pair objects stalled every lane for 50-85 ms a few times per
+        # batch (rocprofv3 trace of the bench); nothing in the loop builds reference cycles worth collecting before it ends.  Only
+        # the oldest generation is held back for the duration of the call -- young collections (cheap, what other threads of the
+        # application may rely on) keep running.
+        gc_thr = gc.get_threshold()
+        gc.set_threshold(gc_thr[0], gc_thr[1], 1 << 30)
         try:
             first = next_prepared(main)
             B = min(slots, -(-len(pairs) // engines))
@@ -334,20 +446,20 @@ class Registration:
             # a failing lane must not leave the producer blocked on the bounded queue, holding device tensors and
             # pinned buffers: stop it, drain what it queued, join it, and let every stream finish what was enqueued
             stop.set()
-            while True:
-                try:
-                    todo.get_nowait()
-                except queue.Empty:
-                    break
-            if th is not None:
+            for q in out_q + in_q:
+                while True:
+                    try:
+                        q.get_nowait()
+                    except queue.Empty:
+                        break
+            for th in threads:
                 th.join()
             torch.cuda.synchronize(dev)
             ctx.preps = ctx.next_prepared = None
             raise
         finally:
-            if gc_was_on:
-                gc.enable()
-        if th is not None:
+            gc.set_threshold(*gc_thr)
+        for th in threads:
             th.join()
         for lane in lanes:
             main.wait_stream(lane.stream)
@@ -385,10 +497,39 @@ class Registration:
                          break_threshold_ratio=c.break_threshold_ratio, w_cd=w_cd, trunc=trunc,
                          w_reg=float(c.w_reg), early_stop=True)
 
-    def _prepare(self, src_pcd, tgt_pcd, landmarks):
+    def _init_ops(self, descs, depth, stride):
+        """ctypes draw ops of one pair's pyramid initialisation (cached per configuration)."""
+        key = (tuple(descs), depth, stride)
+        cache = self.__dict__.setdefault("_ops_cache", {})
+        if key not in cache:
+            cache[key] = N.make_draw_ops(_draw_ops(descs, depth, stride))
+        return cache[key]
+
+    def _pair_descs(self):
+        c = self.config
+        gate = c.w_reg > 0                                                          # registration.py:138
+        desc = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format, nonrigidity=gate)
+        level0 = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format)
+        return desc, [level0] + [desc] * (c.m - 1)                                  # nets.py:26: level 0 never carries the gate
+
+    def _pair_draws(self, n_src, n_tgt):
+        """Raw generator draws one pair consumes: pyramid init + randperm(n_src) + randperm(n_tgt)."""
+        desc, descs = self._pair_descs()
+        ops_ = self._init_ops(descs, self.config.depth, (desc.param_count + 63) // 64 * 64)
+        return int(N.host_lib().ndp_pair_draws(ops_, len(ops_), int(n_src), int(n_tgt)))
+
+    def _pin_ring(self, key):
+        rings = self.__dict__.setdefault("_pin_rings", {})
+        if key not in rings:
+            rings[key] = _PinRing()
+        return rings[key]
+
+    def _prepare(self, src_pcd, tgt_pcd, landmarks, rng_state=None, ring=None):
         """Host side of registration.py:133-164 for one pair: RNG replay of the pyramid initialisation and of the two
         sampling permutations into ONE pinned buffer, one asynchronous upload, one launch for the two cloud means.
-        Centring, sampling and the slot fill itself happen on the device (k_eng_load)."""
+        Centring, sampling and the slot fill itself happen on the device (k_eng_load).
+        rng_state: a snapshot of torch's CPU generator state this pair starts from (the batched producer's workers; the global
+        generator is then left alone), None: consume the global generator like the reference does.  ring: pinned staging ring."""
         c = self.config
         # (upstream fails deep inside knn_points / mean() on such inputs; say what is wrong instead)
         for name, cloud in (("source", src_pcd), ("target", tgt_pcd)):
@@ -404,27 +545,46 @@ class Registration:
             raise N.NdpError("the HIP kernels are specialised for depth=3, width=128 (NDP.yaml / LNDP.yaml)")
         p = _Prepared()
         # registration.py:133-140 -- all m levels are initialised up front on the CPU generator
-        gate = c.w_reg > 0                                                          # registration.py:138
-        p.desc = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format,
-                           nonrigidity=gate)                                        # engine: "levels > 0 gated"
-        level0 = LayerDesc(width=c.width, n_hidden=c.depth - 1, motion=c.motion_type, rotfmt=c.rotation_format)
+        p.desc, descs = self._pair_descs()                                          # engine: "levels > 0 gated"
         stride = (p.desc.param_count + 63) // 64 * 64
         n_par = c.m * stride
         samples = int(c.samples)
-        host = self._pinned_store(n_par + 2 * samples)                             # reused pinned staging buffer
-        init_pyramid_store([level0] + [p.desc] * (c.m - 1), c.depth, stride, out=host[:n_par].view(c.m, stride))   # nets.py:26
+        ring = ring if ring is not None else self._pin_ring("main")
+        host = ring.take(n_par + 2 * samples)                                      # reused pinned staging buffer
         src_pcd = src_pcd.to(dev, non_blocking=True).float().contiguous()
         tgt_pcd = tgt_pcd.to(dev, non_blocking=True).float().contiguous()
         p.src_pcd, p.tgt_pcd = src_pcd, tgt_pcd
-        perm_s = torch.randperm(src_pcd.shape[0])                                 # :156-159 (CPU RNG)
-        perm_t = torch.randperm(tgt_pcd.shape[0])
-        ns, nt = min(samples, perm_s.shape[0]), min(samples, perm_t.shape[0])
+        n_src, n_tgt = src_pcd.shape[0], tgt_pcd.shape[0]
+        ns, nt = min(samples, n_src), min(samples, n_tgt)
         hi = host[n_par:].view(torch.int32)
-        hi[:ns] = perm_s[:ns]
-        hi[samples:samples + nt] = perm_t[:nt]
+        if _native_rng_ok():
+            # init draws + both permutation prefixes in ONE native call from a generator-state snapshot (GIL released)
+            own = rng_state is None
+            st = torch.get_rng_state() if own else rng_state
+            ops_ = self._init_ops(descs, c.depth, stride)
+            store = host[:n_par].view(c.m, stride)
+            for i, d in enumerate(descs):
+                store[i, d.param_count:] = 0.0
+            scratch = ring.scratch(max(n_src, n_tgt))
+            L = N.host_lib()
+            rc = L.ndp_pair_init(ctypes.c_void_p(st.data_ptr()), st.numel(), ops_, len(ops_), ctypes.c_void_p(host.data_ptr()),
+                                 n_src, n_tgt, samples, ctypes.c_void_p(hi.data_ptr()), ctypes.c_void_p(hi[samples:].data_ptr()),
+                                 ctypes.c_void_p(scratch.data_ptr()))
+            if rc != 0:
+                raise N.NdpError("ndp_pair_init failed")
+            if own:                                                                 # leave the global generator where torch would
+                L.ndp_rng_skip(ctypes.c_void_p(st.data_ptr()), st.numel(), L.ndp_pair_draws(ops_, len(ops_), n_src, n_tgt))
+                torch.set_rng_state(st)
+        else:
+            if rng_state is not None:
+                raise N.NdpError("a generator-state snapshot needs the native RNG replay (libndp_host.so)")
+            init_pyramid_store(descs, c.depth, stride, out=host[:n_par].view(c.m, stride))   # nets.py:26
+            perm_s = torch.randperm(n_src)                                          # :156-159 (CPU RNG)
+            perm_t = torch.randperm(n_tgt)
+            hi[:ns] = perm_s[:ns]
+            hi[samples:samples + nt] = perm_t[:nt]
         p.buf = host.to(dev, non_blocking=True)                                    # async upload on the current stream
-        self._pin_busy.append((host, torch.cuda.Event()))
-        self._pin_busy[-1][1].record(torch.cuda.current_stream(dev))
+        ring.uploaded(host, torch.cuda.current_stream(dev))
         p.store = p.buf[:n_par].view(c.m, stride)
         di = p.buf[n_par:].view(torch.int32)
         p.perm_s, p.perm_t = di[:ns], di[samples:samples + nt]
@@ -443,34 +603,17 @@ class Registration:
         p.result = p.state = None
         return p
 
-    def _pinned_store(self, numel):
-        """A pinned float32 host buffer of `numel` elements whose previous upload has completed (small ring, allocated
-        once: hipHostMalloc costs milliseconds)."""
-        if not hasattr(self, "_pin_free"):
-            self._pin_free, self._pin_busy = [], []
-        while self._pin_busy and self._pin_busy[0][1].query():
-            self._pin_free.append(self._pin_busy.pop(0)[0])
-        for i, buf in enumerate(self._pin_free):
-            if buf.numel() == numel:
-                return self._pin_free.pop(i)
-        if len(self._pin_busy) >= 64:                                               # bound the ring: wait for the oldest
-            host, ev = self._pin_busy.pop(0)
-            ev.synchronize()
-            if host.numel() == numel:
-                return host
-        return torch.empty(numel, dtype=torch.float32).pin_memory()
-
     def _engine(self, B, like, n_hint=0, lane=0):
         n_cap = ops.cap(max(like.K + like.S, n_hint))
         t_cap = ops.cap(max(like.T, self.config.samples if like.S else 0))
         cfg = self._opt_config(like.K > 0)
         desc = like.desc
-        key = (B, n_cap, t_cap, desc, tuple(sorted(vars(cfg).items())))
+        key = (B, n_cap, t_cap, desc, tuple(sorted(vars(cfg).items())), self.gemm_mode, self.nn_mode, self.nn_matrix)
         if self._engines.get("key") != key:
             self._engines.clear()                      # one resident engine configuration at a time
             self._engines["key"] = key
         if lane not in self._engines:
-            self._engines[lane] = BatchedEngine(desc, cfg, B, n_cap, t_cap, self._dev())
+            self._engines[lane] = BatchedEngine(desc, cfg, B, n_cap, t_cap, self._dev(), gemm_mode=self.gemm_mode, nn_mode=self.nn_mode, nn_matrix=self.nn_matrix)
         return self._engines[lane]
 
     def _finish(self, eng, done, freeze=False):

@@ -124,7 +124,8 @@ int ndp_nerfies_bwd(const float *params, const float *x, int n, float *act, cons
  * Node graph: n_nodes positions `nodes` [n][3], axis-angle rotations `phi` [n][3], translations `t` [n][3]; every point has
  * six anchors (`anchors` [S][6] int32, -1 = the LAST node with weight 0, as upstream's negative indexing) with skinning
  * `weights` [S][6]; graph edges `edges` [n][K] int32 (-1 padded the same way) with `edge_w` [n][K].
- * ndp_ed_warp: R_work [n][9] <- axis_angle_to_matrix(phi) ; y = ED_warp(x) (geometry.py:37-49).
+ * ndp_ed_warp: R_work [n][9] <- axis_angle_to_matrix(phi) ; y = ED_warp(x) (geometry.py:37-49).  phi == NULL: R_work is used as it
+ *              is (upstream's final warp runs with the R of the last loop iteration, registration.py:376, 449-453).
  * ndp_ed_arap: out[0] = arap_cost (loss.py:261-285) for the R of the last ndp_ed_warp.
  * ndp_ed_grad: grads [phi (3n) | t (3n)] = d/d(phi, t) of <gy, ED_warp(x)> + w_arap * arap  (gy = dL/dy [S][3], e.g. the
  * Chamfer gradient times w_cd): one workgroup per node, fixed summation order.                                          */
@@ -157,6 +158,9 @@ int ndp_chamfer_nn_onepass(const float *x, int S, const float *y, int T, float *
 int ndp_chamfer_nn_matrix(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y,
                           int *idx_y, float *ws_row, void *stream);
 int ndp_engine_nn_matrix_fits(int n_cap);
+/* 1 when the column table of the one-pass VECTOR kernel (engine nn_mode 0 / ndp_chamfer_nn_onepass) fits LDS for n_cap sources;
+ * beyond that an engine must use nn_mode 1 (latency shape: no table, no size limit).                                                 */
+int ndp_engine_nn_onepass_fits(int n_cap);
 
 /* Truncated L1 Chamfer value and gradient from the NN result (loss.py:185-258 and its autograd):
  * loss[0] = sum_i sqrt(d2x_i)[d2x_i<trunc]/S + sum_j sqrt(d2y_j)[d2y_j<trunc]/T   (point_sum != 0: without the /S, /T --
@@ -278,6 +282,11 @@ int ndp_engine_load(const ndp_engine *e, int tick, const ndp_load_job *jobs, int
  * kernels over the n_ticks ticks.  Synchronises `stream`.  Measurement aid for bench.py (roofline), not a product path. */
 #define NDP_TICK_KERNELS 6
 int ndp_engine_run_timed(const ndp_engine *e, int tick0, int n_ticks, void *stream, float *ms_out);
+
+/* ONE tick, restricted to the launches of stages [stage_lo, stage_hi]: 0 forward, 1 nearest neighbours, 2 loss / decision /
+ * dL/dx', 3 bwd2, 4 bwd1, 5 update.  Test and measurement aid: the buffers a kernel leaves behind (act, heads, dO, gpart) can be
+ * read between stages; the stages 0..5 of a tick run in order, in any grouping, equal ndp_engine_run(e, tick, 1).               */
+int ndp_engine_run_stages(const ndp_engine *e, int tick, int stage_lo, int stage_hi, void *stream);
 
 #ifdef __cplusplus
 }

@@ -47,3 +47,28 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+# The two arithmetic configurations every engine-level parity test runs in (same tolerances for both):
+#   bitwise: level kernels on the fp32 MFMA (the oracle's fma chain) + the vector-pipe nearest-neighbour kernels;
+#   split  : level kernels' 128x128 contractions as three-way bf16 splits on the bf16 MFMA (gemm_mode 7) + the one-pass
+#            nearest-neighbour kernel with the distances on the bf16 matrix pipe (nn_mode 2) wherever its table fits LDS.
+ARITH = ("bitwise", "split")
+
+
+def engine_modes(arith, n_cap=None, nn_mode=None):
+    """BatchedEngine keyword arguments of an arithmetic configuration.  nn_mode: force a shape (None: matrix kernel in
+    `split` when n_cap sources fit it, engine's choice otherwise)."""
+    from deformationpyramid_amd import _native as N
+    from deformationpyramid_amd.ops import cap
+    kw = dict(gemm_mode=7 if arith == "split" else 0)
+    if nn_mode is not None:
+        kw["nn_mode"] = nn_mode
+    elif arith == "split" and n_cap is not None and N.lib().ndp_engine_nn_matrix_fits(cap(max(n_cap, 1))):
+        kw["nn_mode"] = 2
+    return kw
+
+
+def registration_modes(arith):
+    """Registration keyword arguments of an arithmetic configuration."""
+    return dict(gemm_mode=7, nn_matrix=True) if arith == "split" else dict(gemm_mode=0, nn_matrix=False)

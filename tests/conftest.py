@@ -25,3 +25,9 @@ def golden():
         return cache[name]
 
     return load
+
+
+@pytest.fixture(params=["bitwise", "split"])
+def arith(request):
+    """Arithmetic configuration of the engine under test (tests/_helpers.py: ARITH)."""
+    return request.param

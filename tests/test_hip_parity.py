@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._helpers import VARIANTS, seeded_pyramid, scale_heads, rel_err, flat_from_named
+from tests._helpers import VARIANTS, engine_modes, registration_modes, seeded_pyramid, scale_heads, rel_err, flat_from_named
 
 pytestmark = pytest.mark.gpu
 K0 = -8
@@ -195,17 +195,18 @@ def test_landmark_and_adam_bit_exact(dev):
 
 
 # ----------------------------------------------------------------------------- batched engine
-def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3, seed=7, G=None, ratio=0.001, nn_mode=None, gemm_mode=None):
+def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3, seed=7, G=None, ratio=0.001, nn_mode=None, gemm_mode=None, arith=None):
     from deformationpyramid_amd.engine import BatchedEngine, OptConfig
     kw = VARIANTS[tag]
     cfg = OptConfig(m=m, iters=iters, early_stop=early_stop, w_cd=w_cd, trunc=trunc, break_threshold_ratio=ratio)
     eng = None
     refs = []
+    modes = engine_modes(arith, K + S, nn_mode) if arith is not None else dict(nn_mode=nn_mode, gemm_mode=gemm_mode)
     for b in range(B):
         pyr = seeded_pyramid(seed + b, m=m, **kw)
         d = pyr.descs[0]
         if eng is None:
-            eng = BatchedEngine(d, cfg, B, n_cap=K + S, t_cap=max(T, 1), device=dev, G=G, nn_mode=nn_mode, gemm_mode=gemm_mode)
+            eng = BatchedEngine(d, cfg, B, n_cap=K + S, t_cap=max(T, 1), device=dev, G=G, **modes)
         # slots of different sizes: slot b drops 7*b samples and 3*b targets
         Kb, Sb, Tb = K, max(S - 7 * b, 0), max(T - 3 * b, 0)
         src = cloud(Kb + Sb, 100 + b)
@@ -223,9 +224,9 @@ def _engine_vs_oracle(dev, tag, K, S, T, m, iters, early_stop, w_cd, trunc, B=3,
 
 
 @pytest.mark.parametrize("tag", ["se3aa", "sim3eu", "sflow"])
-def test_engine_fixed_work_matches_oracle(dev, tag):
+def test_engine_fixed_work_matches_oracle(dev, tag, arith):
     """Early stop off, 6 iterations x 2 levels: same number of steps, parameters and points agree."""
-    eng, states, refs = _engine_vs_oracle(dev, tag, K=0, S=300, T=280, m=2, iters=6, early_stop=False, w_cd=1.0, trunc=1e9)
+    eng, states, refs = _engine_vs_oracle(dev, tag, K=0, S=300, T=280, m=2, iters=6, early_stop=False, w_cd=1.0, trunc=1e9, arith=arith)
     P = eng.P
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert st.level == 2 and list(st.evals_per_level[:2]) == [6, 6] and st.total_steps == 12
@@ -239,9 +240,9 @@ def test_engine_fixed_work_matches_oracle(dev, tag):
         assert np.abs(pts - ref["pts"]).max() < 1e-4                     # north_star: warped coordinates
 
 
-def test_engine_early_stop_counts_match_oracle(dev):
+def test_engine_early_stop_counts_match_oracle(dev, arith):
     eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=256, T=256, m=3, iters=60, early_stop=True,
-                                          w_cd=1.0, trunc=1e9, ratio=0.01)
+                                          w_cd=1.0, trunc=1e9, ratio=0.01, arith=arith)
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert st.level == 3
         assert list(st.evals_per_level[:3]) == list(ref["iters_per_level"]), (b, list(st.evals_per_level[:3]), ref["iters_per_level"])
@@ -249,19 +250,19 @@ def test_engine_early_stop_counts_match_oracle(dev):
         assert np.abs(pts - ref["pts"]).max() < 5e-4
 
 
-def test_engine_landmark_only_and_mixed(dev):
-    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=150, S=0, T=0, m=2, iters=5, early_stop=False, w_cd=0.0, trunc=0.25)
+def test_engine_landmark_only_and_mixed(dev, arith):
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=150, S=0, T=0, m=2, iters=5, early_stop=False, w_cd=0.0, trunc=0.25, arith=arith)
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert st.total_steps == 10
         assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
         assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
-    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=70, S=200, T=222, m=2, iters=4, early_stop=False, w_cd=0.5, trunc=0.05)
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=70, S=200, T=222, m=2, iters=4, early_stop=False, w_cd=0.5, trunc=0.05, arith=arith)
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
         assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
 
 
-def test_F9c_engine_mixed_objective_against_the_reference(dev, golden):
+def test_F9c_engine_mixed_objective_against_the_reference(dev, golden, arith):
     """The mixed landmark + truncated-Chamfer objective (registration.py:189-197) through the HIP engine, against the
     trace captured from the reference: loss of evaluations 1..8 and the parameters after three Adam steps."""
     from deformationpyramid_amd.engine import BatchedEngine, OptConfig
@@ -273,13 +274,13 @@ def test_F9c_engine_mixed_objective_against_the_reference(dev, golden):
     d = pyr.descs[0]
     for n_eval in (1, 4, 8):
         cfg = OptConfig(m=1, iters=n_eval, early_stop=False, w_cd=float(g["w_cd"]), trunc=float(g["trunc"]))
-        eng = BatchedEngine(d, cfg, 1, n_cap=K + S, t_cap=T, device=dev)
+        eng = BatchedEngine(d, cfg, 1, n_cap=K + S, t_cap=T, device=dev, **engine_modes(arith, K + S))
         eng.load(0, pts, K, S, torch.from_numpy(g["tgt_ldmk"]), torch.from_numpy(g["t_sample"]), pyr.store[:1])
         st = eng.run_until_done(chunk=n_eval)[0]
         assert st.total_evals == n_eval
         assert abs(st.loss - ref[n_eval - 1]) < (2e-6 if n_eval == 1 else 1e-3) * ref[n_eval - 1], (n_eval, st.loss, ref[n_eval - 1])
     cfg = OptConfig(m=1, iters=3, early_stop=False, w_cd=float(g["w_cd"]), trunc=float(g["trunc"]))
-    eng = BatchedEngine(d, cfg, 1, n_cap=K + S, t_cap=T, device=dev)
+    eng = BatchedEngine(d, cfg, 1, n_cap=K + S, t_cap=T, device=dev, **engine_modes(arith, K + S))
     eng.load(0, pts, K, S, torch.from_numpy(g["tgt_ldmk"]), torch.from_numpy(g["t_sample"]), pyr.store[:1])
     eng.run_until_done(chunk=3)
     got = eng.params[0, 0, :d.param_count].cpu().numpy()
@@ -289,7 +290,7 @@ def test_F9c_engine_mixed_objective_against_the_reference(dev, golden):
         assert np.abs(got[off:off + ref3.size].reshape(ref3.shape) - ref3)[mask].max() < 2e-4, name
 
 
-def test_F13_shape_transfer_on_the_engine_against_the_reference(dev, golden):
+def test_F13_shape_transfer_on_the_engine_against_the_reference(dev, golden, arith):
     """BASELINE config 4 against reference data: Sim3 / euler, 6000 + 6000 seeded mesh vertices, ten iterations of level 0
     (loss of evaluations 1 and 10), then all 24 856 source vertices through the nine levels (1e-4 on coordinates)."""
     from deformationpyramid_amd import ops
@@ -300,7 +301,7 @@ def test_F13_shape_transfer_on_the_engine_against_the_reference(dev, golden):
     S, T = g["s_sample"].shape[0], g["t_sample"].shape[0]
     ref = g["losses"]
     for n_eval in (1, 10):
-        eng = BatchedEngine(d, OptConfig(m=1, iters=n_eval, early_stop=False), 1, n_cap=S, t_cap=T, device=dev)
+        eng = BatchedEngine(d, OptConfig(m=1, iters=n_eval, early_stop=False), 1, n_cap=S, t_cap=T, device=dev, **engine_modes(arith, S))
         eng.load(0, torch.from_numpy(g["s_sample"]), 0, S, None, torch.from_numpy(g["t_sample"]), pyr.store[:1])
         st = eng.run_until_done(chunk=n_eval)[0]
         assert abs(st.loss - ref[n_eval - 1]) < (2e-6 if n_eval == 1 else 2e-3) * ref[n_eval - 1], (n_eval, st.loss, ref[n_eval - 1])
@@ -346,11 +347,11 @@ def test_chamfer_point_reduction_sum(dev):
     assert mean.item() < got.item() / 200
 
 
-def test_engine_is_deterministic_and_G_independent_in_loss(dev):
-    e1, s1, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=2)
-    e2, s2, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=2)
+def test_engine_is_deterministic_and_G_independent_in_loss(dev, arith):
+    e1, s1, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=2, arith=arith)
+    e2, s2, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=2, arith=arith)
     assert torch.equal(e1.params, e2.params)                              # bit-reproducible run to run
-    e3, s3, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=8)
+    e3, s3, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=500, T=400, m=2, iters=5, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=8, arith=arith)
     assert abs(s1[0].loss - s3[0].loss) < 1e-5 * abs(s1[0].loss)
 
 
@@ -383,14 +384,14 @@ def test_gate_forward_backward_matches_oracle_and_reference(dev, golden, tag):
     assert np.abs(full - g[f"{tag}.full_out"]).max() < 1e-4
 
 
-def test_engine_with_bce_regulariser_matches_oracle(dev, golden):
+def test_engine_with_bce_regulariser_matches_oracle(dev, golden, arith):
     from deformationpyramid_amd.engine import BatchedEngine, OptConfig
     from deformationpyramid_amd.layout import LayerDesc
     g = golden("F11_nonrigidity")
     m, iters, w_reg = 3, 5, 0.5
     gated = LayerDesc(nonrigidity=True)
     cfg = OptConfig(m=m, iters=iters, early_stop=False, w_reg=w_reg)
-    eng = BatchedEngine(gated, cfg, 2, n_cap=300, t_cap=280, device=dev)
+    eng = BatchedEngine(gated, cfg, 2, n_cap=300, t_cap=280, device=dev, **engine_modes(arith, 300))
     refs = []
     for b in range(2):
         pyr = seeded_pyramid(int(g["it.seed"]) + b, m=m, nonrigidity_est=True, **VARIANTS["se3aa"])
@@ -407,7 +408,7 @@ def test_engine_with_bce_regulariser_matches_oracle(dev, golden):
         assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
 
 
-def test_register_with_w_reg_runs_end_to_end(dev, golden):
+def test_register_with_w_reg_runs_end_to_end(dev, golden, arith):
     import os
     from deformationpyramid_amd.config import Config, load_config
     from deformationpyramid_amd.registration import Registration
@@ -417,7 +418,7 @@ def test_register_with_w_reg_runs_end_to_end(dev, golden):
     c = Config(load_config(os.path.join(root, "config", "NDP.yaml"), device=0), samples=256, w_reg=0.3, m=5)
     src, tgt, _, _ = synthetic_pair(11, n_total=2048)
     torch.manual_seed(4)
-    model = Registration(c)
+    model = Registration(c, **registration_modes(arith))
     model.load_pcds(src.numpy(), tgt.numpy())
     warped, cnt, _ = model.register()
     counts = np.array([cnt[l] for l in range(5)])
@@ -427,11 +428,11 @@ def test_register_with_w_reg_runs_end_to_end(dev, golden):
 
 
 # ------------------------------------------------------------------- BASELINE.json configs 4 and 5 as parity cases
-def test_config4_shape_transfer_sizes_sim3_euler(dev):
+def test_config4_shape_transfer_sizes_sim3_euler(dev, arith):
     """shape_transfer.py: Sim3 / euler, ALL 6000 surface samples per cloud, then a 24 856-vertex inference warp."""
     from deformationpyramid_amd import ops
     eng, states, refs = _engine_vs_oracle(dev, "sim3eu", K=0, S=6000, T=6000, m=2, iters=3, early_stop=False,
-                                          w_cd=1.0, trunc=1e9, B=1)
+                                          w_cd=1.0, trunc=1e9, B=1, arith=arith)
     st, ref = states[0], refs[0]
     assert st.total_steps == 6
     assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
@@ -443,10 +444,10 @@ def test_config4_shape_transfer_sizes_sim3_euler(dev):
     assert np.abs(got - want).max() < 1e-5
 
 
-def test_config5_lndp_sizes(dev):
+def test_config5_lndp_sizes(dev, arith):
     """LNDP.yaml: K = 500 precomputed landmark correspondences, m = 10 levels, no Chamfer (w_cd = 0)."""
     eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=500, S=0, T=0, m=10, iters=3, early_stop=False,
-                                          w_cd=0.0, trunc=0.25, B=2)
+                                          w_cd=0.0, trunc=0.25, B=2, arith=arith)
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert st.level == 10 and st.total_steps == 30
         assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
@@ -634,14 +635,16 @@ def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name, matrix):
         np.testing.assert_array_equal(iy, r["idx_y"])
 
 
-@pytest.mark.parametrize("nn_mode", [0, 1, 2])
-def test_engine_matches_oracle_at_the_bench_geometry(dev, nn_mode):
-    """What bench.py times: S = T = 2000 samples, G = 4 workgroups per pair, 8 resident pairs of slightly different sizes,
-    3 iterations x 2 levels -- with the one-pass nearest-neighbour kernel (nn_mode 0, the throughput shape) and with the
-    latency shape (nn_mode 1): identical step counts, loss and warped samples within the per-step budget."""
+@pytest.mark.parametrize("arith,nn_mode,G", [("bitwise", 0, 4), ("bitwise", 1, 4), ("bitwise", 2, 4),
+                                             ("split", 2, 2), ("split", 0, 2), ("split", 1, 2)])
+def test_engine_matches_oracle_at_the_bench_geometry(dev, arith, nn_mode, G):
+    """What bench.py times: S = T = 2000 samples, 8 resident pairs of slightly different sizes, 3 iterations x 2 levels, G
+    workgroups per pair as the bench's 128-slot engines get them (4 four-wave workgroups with the fp32-MFMA level kernels,
+    2 eight-wave workgroups with the bf16-split ones) -- with each nearest-neighbour kernel (0 one-pass on the vector pipe, 1
+    latency shape, 2 one-pass on the matrix pipe): identical step counts, loss and warped samples within the per-step budget."""
     eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=2000, T=2000, m=2, iters=3, early_stop=False,
-                                          w_cd=1.0, trunc=1e9, B=8, G=4, nn_mode=nn_mode)
-    assert eng.G == 4 and eng.c_engine.nn_mode == nn_mode
+                                          w_cd=1.0, trunc=1e9, B=8, G=G, nn_mode=nn_mode, arith=arith)
+    assert eng.G == G and eng.c_engine.nn_mode == nn_mode and eng.c_engine.gemm_mode == (7 if arith == "split" else 0)
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert st.level == 2 and st.total_steps == 6
         assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
@@ -688,21 +691,21 @@ def test_engine_on_bf16_splits_stays_inside_the_parity_budget(dev, tag, gemm_mod
     assert (acts[0][1][..., :16] - acts[1][1][..., :16]).abs().max().item() < 1e-8
 
 
-def test_config3_stress_samples_8192(dev):
+def test_config3_stress_samples_8192(dev, arith):
     """BASELINE config 3 (samples = 8192, Chamfer-bound): S = T = 8192 in the engine, two slots of different sizes."""
     eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=8192, T=8192, m=2, iters=2, early_stop=False,
-                                          w_cd=1.0, trunc=1e9, B=2)
+                                          w_cd=1.0, trunc=1e9, B=2, arith=arith)
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert st.level == 2 and st.total_steps == 4
         assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
         assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
 
 
-def test_config2_fixed_work_450_iterations_per_pair(dev):
+def test_config2_fixed_work_450_iterations_per_pair(dev, arith):
     """early stop off, 50 iterations x 9 levels = exactly 450 Adam steps per pair; the
     loss trace of the whole run stays within the per-step budget of the oracle's (small clouds keep the oracle fast)."""
     eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=256, T=240, m=9, iters=50, early_stop=False,
-                                          w_cd=1.0, trunc=1e9, B=2)
+                                          w_cd=1.0, trunc=1e9, B=2, arith=arith)
     for b, (st, ref) in enumerate(zip(states, refs)):
         assert st.level == 9 and st.total_steps == 450 and st.total_evals == 450
         assert list(st.evals_per_level[:9]) == [50] * 9

@@ -137,8 +137,8 @@ def test_metrics_nan_on_empty_subset_like_upstream():
 def test_timers_and_meters_protocol():
     from deformationpyramid_amd.utils import Timers, AverageMeter
     t = Timers()
-    t.tic("registration"); t.toc("registration"); t.tictoc("ndp_engine", 0.5)
-    assert t.get_avg("ndp_engine") == 0.5 and len(t.get_strings()) == 2
+    t.tic("registration"); t.toc("registration"); t.tictoc("backprop", 0.5)
+    assert t.get_avg("backprop") == 0.5 and len(t.get_strings()) == 2
     a = AverageMeter()
     a.update(2.0); a.update(4.0)
     assert a.avg == 3.0 and a.count == 2
@@ -189,6 +189,33 @@ def test_two_rank_gloo_aggregation():
                           "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "tests", "_gloo_worker.py")],
                          capture_output=True, text=True, env=env, timeout=240)
     assert "AGG_OK" in out.stdout, out.stdout + out.stderr
+
+
+def test_eight_rank_gloo_bench_aggregation():
+    """The aggregation path bench.py runs at --gpus 8, on CPU: 8 gloo ranks, different pair counts, skewed elapsed times;
+    whole-job value = sum of pairs / slowest rank, per-rank figures out of the SAME single all-reduce."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8",
+                          "--master-addr", "127.0.0.1", "--master-port", "29523", os.path.join(ROOT, "tests", "_gloo_worker8.py")],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert "AGG8_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_rank_affinity_plan_keeps_ranks_on_their_gpu_numa_node_and_apart():
+    from deformationpyramid_amd.parallel import _parse_cpulist, plan_affinity
+    assert _parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    topo = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    nodes = [0, 0, 0, 0, 1, 1, 1, 1]                       # 8 GPUs, 4 per socket
+    sets = [plan_affinity(r, 8, nodes, lambda n: topo.get(n, []), set(range(256))) for r in range(8)]
+    for r, cs in enumerate(sets):
+        assert len(cs) == 32 and cs <= set(topo[nodes[r]])
+    assert all(sets[a].isdisjoint(sets[b]) for a in range(8) for b in range(a))
+    # restricted cgroup: only what is allowed is used; unknown topology: disjoint slices of the allowed set
+    cs = plan_affinity(5, 8, nodes, lambda n: topo.get(n, []), set(range(60, 70)))
+    assert cs and cs <= set(range(64, 70))
+    sets = [plan_affinity(r, 4, [-1] * 4, lambda n: [], set(range(16))) for r in range(4)]
+    assert [len(c) for c in sets] == [4] * 4 and set().union(*sets) == set(range(16))
+    assert plan_affinity(0, 1, [3], lambda n: [], {7}) == {7}    # node known but no cpulist: stay where we are
 
 
 def test_native_rng_replay_matches_torch():

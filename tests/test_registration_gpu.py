@@ -9,6 +9,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests._helpers import registration_modes
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -21,7 +23,7 @@ def cfg():
     return load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
 
 
-def test_register_matches_reference_end_to_end_small(cfg, golden):
+def test_register_matches_reference_end_to_end_small(cfg, golden, arith):
     from deformationpyramid_amd.config import Config
     from deformationpyramid_amd.loss import compute_flow_metrics
     from deformationpyramid_amd.registration import Registration
@@ -29,11 +31,16 @@ def test_register_matches_reference_end_to_end_small(cfg, golden):
     g = golden("F7_end_to_end")
     c = Config(cfg, samples=256)
     torch.manual_seed(0)
-    model = Registration(c)
+    model = Registration(c, **registration_modes(arith))
     model.load_pcds(g["src"], g["tgt"])
     timer = Timers()
     warped, iter_cnt, timer2 = model.register(timer=timer)
-    assert timer2 is timer and "ndp_engine" in timer.timers
+    # the reference's timer keys (registration.py:207-213, 234-238): one call per loss evaluation / per Adam step
+    assert timer2 is timer and list(timer.timers) == ["lvl_warp", "Chamfer", "backprop"]
+    st = model.last_state
+    assert timer.timers["lvl_warp"].calls == timer.timers["Chamfer"].calls == st.total_evals == sum(iter_cnt.values())
+    assert timer.timers["backprop"].calls == st.total_steps
+    assert all(0.0 < timer.timers[k].total_time < 5.0 for k in timer.timers)
     assert warped.shape == (1024, 3) and warped.is_cuda and not warped.requires_grad
     assert torch.equal(model.src_pcd.cpu(), torch.from_numpy(g["src"]))            # un-centred source kept
     counts = np.array([iter_cnt[l] for l in range(9)])
@@ -55,16 +62,18 @@ def test_register_matches_reference_end_to_end_small(cfg, golden):
     assert abs(m["vis-epe"] - ref["vis-epe"]) < 0.3 * ref["vis-epe"]
 
 
-def test_register_landmarks_end_to_end(cfg, golden):
+def test_register_landmarks_end_to_end(cfg, golden, arith):
     from deformationpyramid_amd.config import load_config
     from deformationpyramid_amd.config import Config
     from deformationpyramid_amd.registration import Registration
     g = golden("F9b_lndp_end_to_end")
     c = Config(load_config(os.path.join(ROOT, "config", "LNDP.yaml"), device=0), samples=256)
     torch.manual_seed(0)
-    model = Registration(c)
+    model = Registration(c, **registration_modes(arith))
     model.load_pcds(g["src"], g["tgt"], landmarks=(torch.from_numpy(g["ldmk_s"]), torch.from_numpy(g["ldmk_t"])))
-    warped, iter_cnt, _ = model.register()
+    from deformationpyramid_amd.utils import Timers
+    warped, iter_cnt, timer = model.register(timer=Timers())
+    assert list(timer.timers) == ["backprop"] and timer.timers["backprop"].calls == model.last_state.total_steps   # upstream tics only this key with landmarks
     counts = np.array([iter_cnt[l] for l in range(10)])
     assert abs(int(counts.sum()) - int(g["iters_per_level"].sum())) < 0.5 * g["iters_per_level"].sum()
     assert abs(model.last_state.loss - g["loss_trace"][-1]) < 0.25 * g["loss_trace"][-1]
@@ -75,7 +84,7 @@ def test_register_landmarks_end_to_end(cfg, golden):
     assert abs(flow_err - ref_err) < 0.1 * ref_err + 1e-3
 
 
-def test_register_batch_reproduces_reference_benchmark_metrics(cfg, golden):
+def test_register_batch_reproduces_reference_benchmark_metrics(cfg, golden, arith):
     """F10: the reference's metric rows on 8 synthetic 8192-pt pairs (seed p per pair)."""
     from deformationpyramid_amd.loss import compute_flow_metrics
     from deformationpyramid_amd.registration import Registration
@@ -83,7 +92,7 @@ def test_register_batch_reproduces_reference_benchmark_metrics(cfg, golden):
     g = golden("F10_benchmark")
     keys = list(g["keys"])
     rows, iters = [], []
-    model = Registration(cfg)
+    model = Registration(cfg, **registration_modes(arith))
     for p in range(len(g["seeds"])):
         src, tgt, flow_gt, overlap = synthetic_pair(p)
         torch.manual_seed(p)                                   # the fixture seeds per pair
@@ -104,7 +113,7 @@ def test_register_batch_reproduces_reference_benchmark_metrics(cfg, golden):
     assert abs(np.mean(iters) - g["iters"].sum(1).mean()) < 0.25 * g["iters"].sum(1).mean()
 
 
-def test_register_reproduces_reference_metrics_on_surface_pairs(cfg, golden):
+def test_register_reproduces_reference_metrics_on_surface_pairs(cfg, golden, arith):
     """F10b: 8 seeded pairs of partial-overlap SURFACE samples on which the reference reaches full-EPE 5-6 (zero flow:
     10-13) and AccS ~40 %.  The 8-pair means of the GPU path must sit within 10 % of the reference's, and the do-nothing
     answers (zero flow, centroid shift) must FAIL the same assert -- the bar discriminates."""
@@ -120,7 +129,7 @@ def test_register_reproduces_reference_metrics_on_surface_pairs(cfg, golden):
         pairs.append((src, tgt))
         gts.append((flow_gt, overlap))
     rows = []
-    model = Registration(cfg)
+    model = Registration(cfg, **registration_modes(arith))
     for p, (src, tgt) in zip(g["seeds"], pairs):
         torch.manual_seed(int(p))                              # the fixture seeds per pair
         model.load_pcds(src.numpy(), tgt.numpy())
@@ -137,7 +146,7 @@ def test_register_reproduces_reference_metrics_on_surface_pairs(cfg, golden):
     assert not within(g["zero_flow_rows"]) and not within(g["centroid_rows"])
 
 
-def test_register_batch_equals_sequential_register(cfg):
+def test_register_batch_equals_sequential_register(cfg, arith):
     """Same seed, same pairs: the batched path consumes the CPU RNG in the same order as sequential
     register() calls and lands on the same answer up to trajectory noise; with prefetch on or off the
     result is bit-identical."""
@@ -150,17 +159,18 @@ def test_register_batch_equals_sequential_register(cfg):
         src, tgt, _, _ = synthetic_pair(20 + p, n_total=1500 + 64 * p)
         pairs.append((src, tgt))
     torch.manual_seed(3)
-    a = Registration(c).register_batch(pairs, slots=2, prefetch=True)
+    kw = registration_modes(arith)
+    a = Registration(c, **kw).register_batch(pairs, slots=2, prefetch=True)
     torch.manual_seed(3)
-    b = Registration(c).register_batch(pairs, slots=2, prefetch=False)
+    b = Registration(c, **kw).register_batch(pairs, slots=2, prefetch=False)
     for (wa, ca), (wb, cb) in zip(a, b):
         assert torch.equal(wa, wb) and ca == cb
     torch.manual_seed(3)
-    e2 = Registration(c).register_batch(pairs, slots=2, engines=2, chunk=3)     # two engines on two streams, same G
+    e2 = Registration(c, **kw).register_batch(pairs, slots=2, engines=2, chunk=3)     # two engines on two streams, same G
     for (wa, ca), (wb, cb) in zip(a, e2):
         assert torch.equal(wa, wb) and ca == cb
     torch.manual_seed(3)
-    model = Registration(c)
+    model = Registration(c, **kw)
     for (src, tgt), (wa, ca) in zip(pairs, a):
         model.load_pcds(src, tgt)
         w, cnt, _ = model.register()
