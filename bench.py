@@ -498,6 +498,8 @@ def main():
                                              zero_flow={"full-epe": 13.36, "full-AccS": 0.83})
     if single and not args.no_latency and args.config == "A":
         out["latency"] = latency_profile(cfg, pairs, gemm_mode=main_modes[0])
+        if main_modes[0] in (0, 7):                            # and the other arithmetic at batch 1, fewer repeats
+            out["latency"]["alt"] = latency_profile(cfg, pairs, repeats=3, gemm_mode=7 - main_modes[0])
     if single and not args.no_cpu_baseline and args.config == "A":
         out["cpu_baseline"] = cpu_baseline(cfg, pairs)
     if rank == 0:

@@ -1208,6 +1208,9 @@ k_eng_fwd(ndp_engine e, int parity) {
 }
 
 #include "ndp_fwd_bf16.inc"
+#ifdef NDP_EXPERIMENT_FWD_AS      /* tools/experiments/ndp_fwd_as.inc: activation-stationary bf16 forward -- correct, not faster */
+#include "../../tools/experiments/ndp_fwd_as.inc"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // One-pass exact 1-NN for the engine: every squared distance d2(x_i, y_j) is evaluated ONCE and serves both
@@ -2385,6 +2388,17 @@ extern "C" int ndp_adam_step(float *params, const float *grads, float *m, float 
     return 0;
 }
 
+// workgroups per pair of the bf16 level kernels, and whether the forward among them is the activation-stationary one
+static int engine_g8(const ndp_engine *e) { return e->gemm_mode == 7 ? e->G : (e->G > 1 ? e->G / 2 : 1); }
+static bool engine_fwd_as(const ndp_engine *e) {
+#ifdef NDP_EXPERIMENT_FWD_AS
+    return (e->gemm_mode & 1) && (e->n_cap / NDP_TILE) >= 4 * engine_g8(e);
+#else
+    (void)e;
+    return false;
+#endif
+}
+
 // one tick = NDP_TICK_KERNELS launches; ev (optional): NDP_TICK_KERNELS + 1 events per tick recorded around them
 // stages [stage_lo, stage_hi] of every tick: 0 forward, 1 nearest neighbours, 2 loss / decision / dL/dx', 3 bwd2, 4 bwd1, 5 update
 static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipStream_t s, hipEvent_t *ev, int stage_lo = 0, int stage_hi = NDP_TICK_KERNELS - 1) {
@@ -2414,9 +2428,14 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     const dim3 g_lvl(e->G, e->B);
     // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
     // partials per pair); in a mixed configuration they take half the fp32 grid and zero the partials they do not write.
-    const dim3 g_fwd8(e->gemm_mode == 7 ? e->G : (e->G > 1 ? e->G / 2 : 1), e->B);
+    const dim3 g_fwd8(engine_g8(e), e->B);
     if (e->gemm_mode < 0 || e->gemm_mode > 7) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on bf16 splits");
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
+    const bool fwd_as = engine_fwd_as(e);
+    (void)fwd_as;
+#ifdef NDP_EXPERIMENT_FWD_AS
+    if (fwd_as) if (int rc = set_smem((const void *)k_eng_fwd_as, kSmemFwdAsBytes)) return rc;
+#endif
     if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd18Bytes)) return rc;
     if (e->gemm_mode & 4) if (int rc = set_smem((const void *)k_eng_bwd2_8, kSmemBwd8Bytes)) return rc;
     const dim3 g_nn(nn1_row_chunks(e->t_cap), e->B);
@@ -2432,6 +2451,10 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         NDP_EV();
         if (!NDP_ST(0)) {}
         else if (e->gemm_mode & 1) {
+#ifdef NDP_EXPERIMENT_FWD_AS
+            if (fwd_as) hipLaunchKernelGGL(k_eng_fwd_as, g_fwd8, dim3(512), kSmemFwdAsBytes, s, *e, parity);
+            else
+#endif
             hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity);
             hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
         }

@@ -85,12 +85,13 @@ def test_register_landmarks_end_to_end(cfg, golden, arith):
 
 
 def test_register_batch_reproduces_reference_benchmark_metrics(cfg, golden, arith):
-    """F10: the reference's metric rows on 8 synthetic 8192-pt pairs (seed p per pair)."""
+    """F10: the reference's metric rows on 32 synthetic 8192-pt pairs (seed p per pair) -- the size SURVEY section 8(c) asks for."""
     from deformationpyramid_amd.loss import compute_flow_metrics
     from deformationpyramid_amd.registration import Registration
     from deformationpyramid_amd.synthetic import synthetic_pair
     g = golden("F10_benchmark")
     keys = list(g["keys"])
+    assert len(g["seeds"]) == 32
     rows, iters = [], []
     model = Registration(cfg, **registration_modes(arith))
     for p in range(len(g["seeds"])):
@@ -103,14 +104,14 @@ def test_register_batch_reproduces_reference_benchmark_metrics(cfg, golden, arit
         iters.append(sum(cnt.values()))
     rows = np.array(rows)
     ref = g["rows"]
-    # Calibration of the bar (8 pairs, chaotic trajectories): the parity-pinned CPU oracle gives
-    # full/vis/occ-epe = 15.09 / 11.50 / 25.71 and outlier 85.4 where the reference gives
-    # 14.40 / 10.70 / 25.36 and 82.9 -- i.e. a faithful fp32 restatement already differs by up to 7.5 %
-    # in the 8-pair mean (single pairs by up to 50 %: pair 7 vis-epe 12.96 vs 8.67).
+    # Calibration of the bar (32 pairs, chaotic trajectories): the parity-pinned CPU oracle's 32-pair means sit 0.9 % / 1.5 % /
+    # 0.2 % / 0.7 % from the reference's (full / vis / occ-epe, outlier: 14.92 / 11.28 / 25.77 / 84.1 vs 14.78 / 11.12 / 25.72 /
+    # 83.6; with 8 pairs it was 4.8 % / 7.5 % / 1.4 % / 3.0 %), single pairs differ by up to 2 EPE points either way, so the mean
+    # of 32 chaotic differences has a standard error of about 1.8 %: 5 % is a three-sigma band (round 2, 8 pairs: 12 %).
     for k in ("full-epe", "vis-epe", "occ-epe", "full-outlier"):
         j = keys.index(k)
-        assert abs(rows[:, j].mean() - ref[:, j].mean()) < 0.12 * ref[:, j].mean(), (k, rows[:, j].mean(), ref[:, j].mean())
-    assert abs(np.mean(iters) - g["iters"].sum(1).mean()) < 0.25 * g["iters"].sum(1).mean()
+        assert abs(rows[:, j].mean() - ref[:, j].mean()) < 0.05 * ref[:, j].mean(), (k, rows[:, j].mean(), ref[:, j].mean())
+    assert abs(np.mean(iters) - g["iters"].sum(1).mean()) < 0.10 * g["iters"].sum(1).mean()
 
 
 def test_register_reproduces_reference_metrics_on_surface_pairs(cfg, golden, arith):

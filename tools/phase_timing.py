@@ -39,6 +39,8 @@ L.ndp_debug_phase_read(buf, 1)
 ms = eng.run_ticks_timed(ticks)
 L.ndp_debug_phase_read(buf, 1)
 tiles = B * (eng.n_cap // 64) * ticks
+if False:
+    pass
 names = {0: "bwd2 load+lds", 1: "bwd2 barrier", 2: "bwd2 mfma(outer+gemm)+db", 3: "bwd2 barrier", 4: "bwd2 epilogue",
          5: "bwd2 barrier", 6: "bwd2 store", 7: "bwd2 barrier",
          24: "bwd1 load+lds", 25: "bwd1 barrier", 26: "bwd1 mfma(outer+gemm)", 27: "bwd1 barrier", 28: "bwd1 dz0 epilogue+db0",
@@ -65,7 +67,28 @@ for lo, n, tag in ((36, wg_grad, "loss gradient workgroup"), (48, wg_dec, "loss 
         if buf[i]:
             print(f"   {lnames.get(i, i):36s} {buf[i] / n:9.0f}  {100.0 * buf[i] / tot:5.1f} %")
 
-if int(os.environ.get("NDP_GEMM_MODE", "0")) & 1:
+if eng.gemm_mode & 4:
+    nm2 = ["top barrier (incl. wait for the requested rows)", "h1 split + h2 tile + dO rows -> LDS", "barrier", "dz2 chain (VALU) + split -> planes", "barrier",
+           "dWh (fp32 MFMA 16x16x4)", "wgrad (48 MFMA 32x32x16)", "dgrad (96 MFMA 16x16x32) + mask + dz1 store", "tail: dW store, bias sums (once)"]
+    tot = sum(buf[i] for i in range(12))
+    print(f"bwd2_8: {tot / tiles:.0f} cycles per tile (thread 0 wall)")
+    for i, nm in enumerate(nm2):
+        print(f"   {nm:52s} {buf[i] / tiles:9.0f}  {100.0 * buf[i] / max(tot, 1):5.1f} %")
+if eng.gemm_mode & 2:
+    nm1 = ["top barrier (incl. wait for the requested rows)", "dz1 / h0 split -> planes", "barrier", "wgrad (48 MFMA 32x32x16)", "dgrad (96 MFMA 16x16x32) + mask + dW0 fma",
+           "tail: dW store, bias sums, dW0 fold (once)"]
+    tot = sum(buf[24 + i] for i in range(12))
+    print(f"bwd1_8: {tot / tiles:.0f} cycles per tile (thread 0 wall)")
+    for i, nm in enumerate(nm1):
+        print(f"   {nm:52s} {buf[24 + i] / tiles:9.0f}  {100.0 * buf[24 + i] / max(tot, 1):5.1f} %")
+if getattr(eng, 'fwd_as', False):
+    f9 = ["stage W1 / W0 (once per workgroup)", "x, sincos, layer-0 operands", "layer 0 (12 MFMA) + h0 store + split", "layer 1 (192 MFMA) + h1 store",
+          "phase barrier", "stage W2 / Wh (once per workgroup)", "h1 read back + split", "layer 2 + heads (240 MFMA) + h2 store", "-", "-", "-"]
+    tot = sum(buf[12 + i] for i in range(11))
+    print(f"fwd_as (activation-stationary): {tot / tiles:.0f} cycles per 64 points (wave 0 wall; a wave's 32-point group = 1/4 of the workgroup's work per 64 points... see below)")
+    for i, nm in enumerate(f9):
+        print(f"   {nm:48s} {buf[12 + i] / tiles:9.0f}  {100.0 * buf[12 + i] / max(tot, 1):5.1f} %")
+elif eng.gemm_mode & 1:
     f8 = ["-", "layer 0 (VALU) + split + planes + h0 store", "barrier", "-", "layer 1 MFMA + epilogue", "barrier", "-",
           "layer 2 MFMA + epilogue", "barrier", "heads (waves 0..3)", "-"]
     tot = sum(buf[12 + i] for i in range(11))
