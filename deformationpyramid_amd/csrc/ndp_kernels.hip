@@ -2217,31 +2217,45 @@ extern "C" int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const 
     return ndp_pyramid_fwd_batch(desc, m, k0, p_stride, &job, 1, stream);
 }
 
-extern "C" int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_stride,
-                                     const ndp_warp_job *jobs, int n_jobs, void *stream) {
+static int pyramid_fwd_batch_impl(const ndp_layer_desc *desc, int m, int k0, int p_stride, const ndp_warp_job *jobs, int n_jobs,
+                                  void *stream, bool split) {
     if (int rc = check_desc(desc)) return rc;
     if (m < 1 || m > NDP_MAX_LEVELS || n_jobs < 0 || (n_jobs > 0 && !jobs) || p_stride < ndp_param_count(desc) || (p_stride & 3))
         return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch: bad arguments");
-    if (int rc = set_smem((const void *)k_pyramid_fwd, kSmemFwdBytes)) return rc;
+    if (split) { if (int rc = set_smem((const void *)k_pyramid_fwd8, kSmemPyr8Bytes)) return rc; }
+    else if (int rc = set_smem((const void *)k_pyramid_fwd, kSmemFwdBytes)) return rc;
+    const int per_wg = NDP_TILE * (split ? P8_TILES : NDP_PYR_TILES);                          // points per workgroup
     for (int j0 = 0; j0 < n_jobs; j0 += NDP_MAX_WARP_JOBS) {
         WarpJobs wj;
         memset(&wj, 0, sizeof wj);
-        int cnt = 0, max_tiles = 0;
+        int cnt = 0, max_wgs = 0;
         for (int j = j0; j < n_jobs && cnt < NDP_MAX_WARP_JOBS; ++j) {
             const ndp_warp_job &q = jobs[j];
             if (q.n < 0 || (q.n > 0 && (!q.params || !q.x || !q.x_out))) return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch: null pointer / negative n");
             if (!aligned16(q.params)) return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch: params must be 16-byte aligned");
             if (q.n == 0) continue;
             wj.j[cnt++] = q;
-            const int tiles = (q.n + NDP_TILE * NDP_PYR_TILES - 1) / (NDP_TILE * NDP_PYR_TILES);   // workgroups of this cloud
-            if (tiles > max_tiles) max_tiles = tiles;
+            const int wgs = (q.n + per_wg - 1) / per_wg;                                          // workgroups of this cloud
+            if (wgs > max_wgs) max_wgs = wgs;
         }
         if (!cnt) continue;
-        hipLaunchKernelGGL(k_pyramid_fwd, dim3(max_tiles, cnt), dim3(256), kSmemFwdBytes, (hipStream_t)stream,
-                           *desc, m, k0, p_stride, wj);
+        if (split) hipLaunchKernelGGL(k_pyramid_fwd8, dim3(max_wgs, cnt), dim3(512), kSmemPyr8Bytes, (hipStream_t)stream, *desc, m, k0, p_stride, wj);
+        else hipLaunchKernelGGL(k_pyramid_fwd, dim3(max_wgs, cnt), dim3(256), kSmemFwdBytes, (hipStream_t)stream, *desc, m, k0, p_stride, wj);
         HIP_TRY(hipGetLastError(), "k_pyramid_fwd launch");
     }
     return 0;
+}
+
+extern "C" int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_stride,
+                                     const ndp_warp_job *jobs, int n_jobs, void *stream) {
+    return pyramid_fwd_batch_impl(desc, m, k0, p_stride, jobs, n_jobs, stream, false);
+}
+
+// The same warp with the engine's split arithmetic (gemm_mode & 1): the 128-wide contractions as three-way bf16 splits on the
+// bf16 MFMA (k_pyramid_fwd8) -- fp32-level accuracy (1e-5 of the fp32-MFMA kernel on warped coordinates), not bitwise the chain.
+extern "C" int ndp_pyramid_fwd_batch_split(const ndp_layer_desc *desc, int m, int k0, int p_stride,
+                                           const ndp_warp_job *jobs, int n_jobs, void *stream) {
+    return pyramid_fwd_batch_impl(desc, m, k0, p_stride, jobs, n_jobs, stream, true);
 }
 
 extern "C" int ndp_pair_means(const float *src, int n_src, const float *tgt, int n_tgt, float *means, void *stream) {

@@ -625,4 +625,5 @@ class Registration:
         for slot, prep in done:
             store = eng.params[slot].clone() if freeze else eng.params[slot]      # [m, p_stride] on device
             jobs.append(prep.warp_job(store))
-        return ops.pyramid_fwd_batch(done[0][1].desc, c.m, c.k0, jobs, device=self._dev())
+        # the final warp runs in the engine's arithmetic: bf16-split contractions with gemm_mode & 1, the fp32 MFMA otherwise
+        return ops.pyramid_fwd_batch(done[0][1].desc, c.m, c.k0, jobs, device=self._dev(), split=bool(eng.gemm_mode & 1))

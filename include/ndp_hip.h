@@ -86,6 +86,11 @@ typedef struct ndp_warp_job {
 #define NDP_MAX_WARP_JOBS 32
 int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_stride,
                           const ndp_warp_job *jobs, int n_jobs, void *stream);
+/* The same warp with the engine's split arithmetic (ndp_engine.gemm_mode & 1): 128-wide contractions as three-way bf16 splits on
+ * the bf16 MFMA, fp32 accumulate; 256 points per workgroup carried through all m levels in LDS.  fp32-level accuracy (within
+ * 1e-5 of ndp_pyramid_fwd_batch on warped coordinates), not bitwise the fma chain.                                              */
+int ndp_pyramid_fwd_batch_split(const ndp_layer_desc *desc, int m, int k0, int p_stride,
+                                const ndp_warp_job *jobs, int n_jobs, void *stream);
 
 /* Per-cloud means (registration.py:150-153: src_pcd.mean(dim=0), tgt_pcd.mean(dim=0)); means[0..2] = source,
  * means[4..6] = target (means[3], means[7] = 0).  Accumulated in double in a fixed order, rounded once.   */
