@@ -34,7 +34,7 @@
 // -DNDP_PHASE_TIMING: experiment builds only (tools/phase_timing.py) -- thread 0 of every workgroup adds the shader
 // cycles it spent in each phase of a tile to g_phase[]; compiled out of the product library.
 #ifdef NDP_PHASE_TIMING
-__device__ unsigned long long g_phase[64];
+__device__ unsigned long long g_phase[96];
 __shared__ unsigned long long pt_acc[12];                 // per-workgroup accumulators (LDS: no global traffic per stamp)
 #define PT_INIT                                           \
     do {                                                  \
@@ -2111,9 +2111,9 @@ static int set_smem(const void *fn, int bytes) {
 
 #ifdef NDP_PHASE_TIMING
 extern "C" int ndp_debug_phase_read(unsigned long long *out64, int reset) {
-    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_phase), sizeof(unsigned long long) * 96) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[64] = {0};
+        unsigned long long z[96] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), z, sizeof z) != hipSuccess) return -1;
     }
     return 0;

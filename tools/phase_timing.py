@@ -34,7 +34,7 @@ for i in range(16, B, 16):
 eng.run_ticks(4)
 torch.cuda.synchronize()
 L = N.lib()
-buf = (ctypes.c_ulonglong * 64)()
+buf = (ctypes.c_ulonglong * 96)()
 L.ndp_debug_phase_read(buf, 1)
 ms = eng.run_ticks_timed(ticks)
 L.ndp_debug_phase_read(buf, 1)
@@ -67,6 +67,14 @@ for lo, n, tag in ((36, wg_grad, "loss gradient workgroup"), (48, wg_dec, "loss 
         if buf[i]:
             print(f"   {lnames.get(i, i):36s} {buf[i] / n:9.0f}  {100.0 * buf[i] / tot:5.1f} %")
 
+if eng.nn_mode == 2:
+    nmn = ["setup: targets + B operands, sources -> LDS, |x|max", "A operands of a 128-source block (x4 per wave)", "distances: 8 tiles x (8 MFMA + row / column minima)",
+           "rows: transposition, best class, exact evaluation", "barrier (waves done with their blocks)", "columns: fold table, exact re-scan of the winning block"]
+    wgs = B * ((eng.t_cap + 255) // 256) * ticks
+    tot = sum(buf[64 + i] for i in range(6))
+    print(f"nn_mx: {tot / wgs:.0f} cycles per workgroup (all sources x 256 targets; thread 0 wall)")
+    for i, nm in enumerate(nmn):
+        print(f"   {nm:58s} {buf[64 + i] / wgs:9.0f}  {100.0 * buf[64 + i] / max(tot, 1):5.1f} %")
 if eng.gemm_mode & 4:
     nm2 = ["top barrier (incl. wait for the requested rows)", "h1 split + h2 tile + dO rows -> LDS", "barrier", "dz2 chain (VALU) + split -> planes", "barrier",
            "dWh (fp32 MFMA 16x16x4)", "wgrad (48 MFMA 32x32x16)", "dgrad (96 MFMA 16x16x32) + mask + dz1 store", "tail: dW store, bias sums (once)"]
@@ -75,6 +83,9 @@ if eng.gemm_mode & 4:
     for i, nm in enumerate(nm2):
         print(f"   {nm:52s} {buf[i] / tiles:9.0f}  {100.0 * buf[i] / max(tot, 1):5.1f} %")
 if eng.gemm_mode & 2:
+    n_arr = max(buf[24 + 8], 1)
+    print("bwd1_8: mean lateness of wave w at the top-of-tile barrier relative to wave 0 (cycles):", [round(buf[24 + w] / n_arr) for w in range(8)])
+if False:
     nm1 = ["top barrier (incl. wait for the requested rows)", "dz1 / h0 split -> planes", "barrier", "wgrad (48 MFMA 32x32x16)", "dgrad (96 MFMA 16x16x32) + mask + dW0 fma",
            "tail: dW store, bias sums, dW0 fold (once)"]
     tot = sum(buf[24 + i] for i in range(12))
