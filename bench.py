@@ -285,7 +285,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--slots", type=int, default=128, help="pairs resident per GPU (= pairs per step per GPU)")
     ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 32 x slots)")
-    ap.add_argument("--chunk", type=int, default=4, help="ticks between host polls")
+    ap.add_argument("--chunk", type=int, default=0, help="ticks between host polls (0: 4, or 8 for the landmark configuration E whose ticks are "
+                                                          "four times shorter -- the per-chunk host work of three lanes must fit under one chunk of GPU work)")
     ap.add_argument("--engines", type=int, default=3, help="independent engines (HIP streams) per GPU, `slots` pairs each")
     ap.add_argument("--config", default="A", choices=list("ABCDE"),
                     help="SURVEY 8(d) workload: A NDP.yaml faithful (the headline line); B fixed work (= --fixed-work); C samples = 8192; "
@@ -372,6 +373,8 @@ def main():
         cfg = load_config(os.path.join(ROOT, "config", "LNDP.yaml"), device=local_rank)
         workload = ("LNDP.yaml (supervised path): 500 synthetic landmark correspondences per 8192-pt pair (noise 0.005), m=10, "
                     "w_cd=0: landmark MSE only, full register() incl. the 8192-pt final warp")
+    if args.chunk <= 0:
+        args.chunk = 8 if args.config == "E" else 4
     NP = args.pairs_per_step or (32 * B if args.config in "ABE" else 8 * B)
     # inputs resident in HBM before the timed region
     pairs, gts = [], []

@@ -149,13 +149,15 @@ class _Lane:
             self.seq += 1
         if self.pending is not None:
             (h, hseq) = self.pending
-            states = eng.wait_snapshot(h)
+            snap = eng.wait_snapshot(h)
             done = []
-            for slot in list(self.active):
-                i, valid_from = self.active[slot]
-                st = states[slot]
-                if hseq < valid_from or st.level < ctx.m:
+            for slot in np.nonzero(snap.level >= ctx.m)[0].tolist():   # finished (or parked) slots only
+                if slot not in self.active:
                     continue
+                i, valid_from = self.active[slot]
+                if hseq < valid_from:
+                    continue
+                st = snap.state(slot)
                 del self.active[slot]
                 ctx.preps[i].state = st
                 done.append((slot, ctx.preps[i]))

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Everything kept under profiles/ for one round, in one gpurun call (results land in gpurun_out/<tag>_*):
-#   bench lines of SURVEY 8(d) configs A..E, rocprofv3 kernel stats of the roofline workload (128 pairs) and of the
-#   batch-1 tick, PMC HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and the SQ counters.
-#   usage (on the GPU box): bash tools/profile_round.sh r02
+#   bench lines of SURVEY 8(d) configs A..E (the default line carries BOTH arithmetics: `value` = the default split path, `alt` = the
+#   bitwise fp32-MFMA path), rocprofv3 kernel stats of the roofline workload (128 pairs per engine tick) in both arithmetics and of
+#   the batch-1 tick, PMC HBM traffic (FETCH_SIZE / WRITE_SIZE in separate passes) and the SQ counters, both arithmetics.
+#   usage (on the GPU box): bash tools/profile_round.sh r03
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=${1:-rXX}
 O=$R/gpurun_out
@@ -12,11 +13,27 @@ python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench_line.err
 for c in B C D E; do
   python bench.py --config $c --steps 2 --warmup 1 > $O/${TAG}_bench_config_$c.json 2> $O/${TAG}_bench_config_$c.err
 done
+python bench.py --slots 64 --engines 1 --steps 2 --warmup 1 --no-alt --no-latency --no-cpu-baseline > $O/${TAG}_bench_batch64.json 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
+# rocprofv3 kernel stats of the tick: default (split) arithmetic, then the bitwise one
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_tick -o tick -- python $R/tools/tick_bench.py 128 24 > $O/${TAG}_prof_tick.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_tick/*.db | head -1) $O/${TAG}_tick_kernel_stats.csv > /dev/null
+NDP_GEMM_MODE=0 NDP_NN_MODE=0 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_tick_bitwise -o tick -- python $R/tools/tick_bench.py 128 24 > $O/${TAG}_prof_tick_bitwise.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_tick_bitwise/*.db | head -1) $O/${TAG}_tick_kernel_stats_bitwise.csv > /dev/null
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_b1 -o b1 -- python $R/tools/tick_bench.py 1 96 > $O/${TAG}_prof_b1.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_b1/*.db | head -1) $O/${TAG}_batch1_kernel_stats.csv > /dev/null
-bash $R/tools/pmc_traffic.sh 128 8 > $O/${TAG}_hbm_traffic_pmc.json 2> $O/${TAG}_hbm_traffic_pmc.err
+# whole bench under the kernel trace (short): share of the tick kernels, the final warps, the slot loads
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_bench -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-alt --no-roofline --no-latency --no-cpu-baseline > $O/${TAG}_prof_bench.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_bench/*.db | head -1) $O/${TAG}_bench_kernel_stats.csv > /dev/null
+# HBM traffic, both arithmetics merged into ONE file (kernel names differ: k_eng_fwd8 / k_eng_fwd ...)
+bash $R/tools/pmc_traffic.sh 128 8 > $O/${TAG}_hbm_split.json 2> $O/${TAG}_hbm_traffic_pmc.err
+NDP_GEMM_MODE=0 NDP_NN_MODE=0 bash $R/tools/pmc_traffic.sh 128 8 > $O/${TAG}_hbm_bitwise.json 2>> $O/${TAG}_hbm_traffic_pmc.err
+python - $O/${TAG}_hbm_split.json $O/${TAG}_hbm_bitwise.json > $O/${TAG}_hbm_traffic_pmc.json <<'PY'
+import json, sys
+a, b = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
+b.update(a)                       # kernels common to both (nn variants aside: update, loss, load) keep the default arithmetic's numbers
+print(json.dumps(b, indent=1))
+PY
 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_pmc.json
+NDP_GEMM_MODE=0 NDP_NN_MODE=0 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_bitwise_pmc.json
 ls -la $O | grep ${TAG}_
