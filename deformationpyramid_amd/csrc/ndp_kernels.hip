@@ -1208,8 +1208,9 @@ k_eng_fwd(ndp_engine e, int parity) {
 }
 
 #include "ndp_fwd_bf16.inc"
-#ifdef NDP_EXPERIMENT_FWD_AS      /* tools/experiments/ndp_fwd_as.inc: activation-stationary bf16 forward -- correct, not faster */
+#if defined(NDP_EXPERIMENT_FWD_AS) || defined(NDP_EXPERIMENT_FWD_AS16)   /* tools/experiments: activation-stationary bf16 forwards */
 #include "../../tools/experiments/ndp_fwd_as.inc"
+#include "../../tools/experiments/ndp_fwd_as16.inc"
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -2405,7 +2406,7 @@ extern "C" int ndp_adam_step(float *params, const float *grads, float *m, float 
 // workgroups per pair of the bf16 level kernels, and whether the forward among them is the activation-stationary one
 static int engine_g8(const ndp_engine *e) { return e->gemm_mode == 7 ? e->G : (e->G > 1 ? e->G / 2 : 1); }
 static bool engine_fwd_as(const ndp_engine *e) {
-#ifdef NDP_EXPERIMENT_FWD_AS
+#if defined(NDP_EXPERIMENT_FWD_AS) || defined(NDP_EXPERIMENT_FWD_AS16)
     return (e->gemm_mode & 1) && (e->n_cap / NDP_TILE) >= 4 * engine_g8(e);
 #else
     (void)e;
@@ -2447,7 +2448,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     const bool fwd_as = engine_fwd_as(e);
     (void)fwd_as;
-#ifdef NDP_EXPERIMENT_FWD_AS
+#if defined(NDP_EXPERIMENT_FWD_AS16)
+    if (fwd_as) if (int rc = set_smem((const void *)k_eng_fwd_as16, kSmemFwdAs16Bytes)) return rc;
+#elif defined(NDP_EXPERIMENT_FWD_AS)
     if (fwd_as) if (int rc = set_smem((const void *)k_eng_fwd_as, kSmemFwdAsBytes)) return rc;
 #endif
     if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd18Bytes)) return rc;
@@ -2465,7 +2468,10 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         NDP_EV();
         if (!NDP_ST(0)) {}
         else if (e->gemm_mode & 1) {
-#ifdef NDP_EXPERIMENT_FWD_AS
+#if defined(NDP_EXPERIMENT_FWD_AS16)
+            if (fwd_as) hipLaunchKernelGGL(k_eng_fwd_as16, g_fwd8, dim3(1024), kSmemFwdAs16Bytes, s, *e, parity);
+            else
+#elif defined(NDP_EXPERIMENT_FWD_AS)
             if (fwd_as) hipLaunchKernelGGL(k_eng_fwd_as, g_fwd8, dim3(512), kSmemFwdAsBytes, s, *e, parity);
             else
 #endif
