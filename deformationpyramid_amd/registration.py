@@ -19,7 +19,6 @@ import ctypes
 import gc
 import queue
 import threading
-import time
 
 import numpy as np
 import torch
