@@ -158,8 +158,9 @@ int ndp_chamfer_nn_onepass(const float *x, int S, const float *y, int T, float *
 /* The one-pass result with the S x T distances on the bf16 MATRIX pipe (the engine's nn_mode 2): |x - y|^2 = |x|^2 + |y|^2 - 2 x.y as
  * one contraction per 32 x 32 tile, every term a three-way bf16 split (two v_mfma_f32_32x32x16_bf16 per 1024 distances); that value
  * only SELECTS candidates -- every candidate within the rounding bound is re-evaluated with the exact fma chain, so d2 and the lowest
- * index are bit-identical to ndp_chamfer_nn_fwd.  S is limited by LDS (sources + column table: NDP_E_UNSUPPORTED beyond;
- * ndp_engine_nn_matrix_fits(n_cap) tells).  ws_row as for ndp_chamfer_nn_onepass.                                        */
+ * index are bit-identical to ndp_chamfer_nn_fwd.  2048 sources are resident in LDS at a time; more are walked in passes (highest
+ * indices first, so the exact comparisons still end on the lowest index): no size limit since round 3
+ * (ndp_engine_nn_matrix_fits(n_cap) is kept and returns 1).  ws_row as for ndp_chamfer_nn_onepass.                           */
 int ndp_chamfer_nn_matrix(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float *d2y,
                           int *idx_y, float *ws_row, void *stream);
 int ndp_engine_nn_matrix_fits(int n_cap);

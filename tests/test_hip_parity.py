@@ -633,6 +633,11 @@ def _nn_case(name):
         x = u(2000)
     elif name == "large":
         y = u(9000); x = u(700, 1.2)
+    elif name == "many_sources":         # more sources than one LDS pass of the matrix kernel holds (2048): 2 full passes + a ragged one
+        y = u(777, 1.1); x = u(5000)
+    elif name == "cross_pass_ties":      # every source three times, 1500 apart: the copies of a target's nearest source sit in different
+        b = u(1500)                      # passes at the SAME exact distance -- the lowest index must win
+        x = torch.cat([b, b, b]); y = u(600, 0.9)
     return x.contiguous(), y.contiguous()
 
 
@@ -650,7 +655,7 @@ def test_chamfer_nn_is_exact_on_adversarial_layouts(dev, name):
 
 
 @pytest.mark.parametrize("name", ["clusters", "far_queries", "plane", "line", "lattice_ties", "single_ref", "identical",
-                                  "skewed", "large", "ragged", "near_ties"])
+                                  "skewed", "large", "ragged", "near_ties", "many_sources", "cross_pass_ties"])
 @pytest.mark.parametrize("matrix", [False, True])
 def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name, matrix):
     """The engine's one-pass kernels (every distance evaluated once, column minima by cross-lane butterflies, second-stage
