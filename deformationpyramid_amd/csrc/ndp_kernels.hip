@@ -46,10 +46,13 @@ __shared__ unsigned long long pt_acc[12];                 // per-workgroup accum
         __syncthreads();                                                                         \
         if (threadIdx.x < 12 && pt_acc[threadIdx.x]) atomicAdd(&g_phase[(base) + threadIdx.x], pt_acc[threadIdx.x]); \
     } while (0)
+#ifndef PT_TID
+#define PT_TID 0                                          /* the stamping thread (wave-specialised experiments look at other waves too) */
+#endif
 #define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter()
 #define PT(id)                                                                  \
     do {                                                                        \
-        if (threadIdx.x == 0) {                                                 \
+        if (threadIdx.x == PT_TID) {                                                 \
             const unsigned long long pt_now = __builtin_readcyclecounter();     \
             pt_acc[(id) % 12] += pt_now - pt_last;                              \
             pt_last = pt_now;                                                   \
@@ -1208,9 +1211,11 @@ k_eng_fwd(ndp_engine e, int parity) {
 }
 
 #include "ndp_fwd_bf16.inc"
-#if defined(NDP_EXPERIMENT_FWD_AS) || defined(NDP_EXPERIMENT_FWD_AS16)   /* tools/experiments: activation-stationary bf16 forwards */
+#if defined(NDP_EXPERIMENT_FWD_AS) || defined(NDP_EXPERIMENT_FWD_AS16) || defined(NDP_EXPERIMENT_FWD_4W) || defined(NDP_EXPERIMENT_FWD_LP)   /* tools/experiments: other shapes of the bf16 forward */
 #include "../../tools/experiments/ndp_fwd_as.inc"
 #include "../../tools/experiments/ndp_fwd_as16.inc"
+#include "../../tools/experiments/ndp_fwd_4w.inc"
+#include "../../tools/experiments/ndp_fwd_lp.inc"
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -2448,7 +2453,11 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     const bool fwd_as = engine_fwd_as(e);
     (void)fwd_as;
-#if defined(NDP_EXPERIMENT_FWD_AS16)
+#if defined(NDP_EXPERIMENT_FWD_LP)
+    if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd_lp, kSmemFwdLpBytes)) return rc;
+#elif defined(NDP_EXPERIMENT_FWD_4W)
+    if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd4w, kSmemFwd4wBytes)) return rc;
+#elif defined(NDP_EXPERIMENT_FWD_AS16)
     if (fwd_as) if (int rc = set_smem((const void *)k_eng_fwd_as16, kSmemFwdAs16Bytes)) return rc;
 #elif defined(NDP_EXPERIMENT_FWD_AS)
     if (fwd_as) if (int rc = set_smem((const void *)k_eng_fwd_as, kSmemFwdAsBytes)) return rc;
@@ -2468,7 +2477,13 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         NDP_EV();
         if (!NDP_ST(0)) {}
         else if (e->gemm_mode & 1) {
-#if defined(NDP_EXPERIMENT_FWD_AS16)
+#if defined(NDP_EXPERIMENT_FWD_LP)
+            if (true) hipLaunchKernelGGL(k_eng_fwd_lp, g_fwd8, dim3(512), kSmemFwdLpBytes, s, *e, parity);
+            else
+#elif defined(NDP_EXPERIMENT_FWD_4W)
+            if (true) hipLaunchKernelGGL(k_eng_fwd4w, g_fwd8, dim3(256), kSmemFwd4wBytes, s, *e, parity);
+            else
+#elif defined(NDP_EXPERIMENT_FWD_AS16)
             if (fwd_as) hipLaunchKernelGGL(k_eng_fwd_as16, g_fwd8, dim3(1024), kSmemFwdAs16Bytes, s, *e, parity);
             else
 #elif defined(NDP_EXPERIMENT_FWD_AS)

@@ -31,12 +31,26 @@ eng = model._engine(B, preps[0])
 eng.load_jobs([p.load_job(b) for b, p in enumerate(preps)][:16])
 for i in range(16, B, 16):
     eng.load_jobs([p.load_job(b) for b, p in enumerate(preps)][i:i + 16])
-eng.run_ticks(4)
+FWD_ONLY = os.environ.get("NDP_PT_FWD_ONLY") == "1"      # timing-only variants with wrong results: the forward stage alone, state untouched
+if not FWD_ONLY:
+    eng.run_ticks(4)
 torch.cuda.synchronize()
 L = N.lib()
 buf = (ctypes.c_ulonglong * 96)()
 L.ndp_debug_phase_read(buf, 1)
-ms = eng.run_ticks_timed(ticks)
+if FWD_ONLY:
+    eng.run_stages(0, 0)
+    torch.cuda.synchronize()
+    L.ndp_debug_phase_read(buf, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(ticks):
+        eng.run_stages(0, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = [e0.elapsed_time(e1), 0, 0, 0, 0, 0]
+else:
+    ms = eng.run_ticks_timed(ticks)
 L.ndp_debug_phase_read(buf, 1)
 tiles = B * (eng.n_cap // 64) * ticks
 if False:
@@ -101,8 +115,16 @@ if getattr(eng, 'fwd_as', False):
         print(f"   {nm:48s} {buf[12 + i] / tiles:9.0f}  {100.0 * buf[12 + i] / max(tot, 1):5.1f} %")
 elif eng.gemm_mode & 1:
     f8 = ["-", "layer 0 (VALU) + split + planes + h0 store", "barrier", "-", "layer 1 MFMA + epilogue", "barrier", "-",
-          "layer 2 MFMA + epilogue", "barrier", "heads (waves 0..3)", "-"]
+          "layer 2 MFMA + epilogue", "barrier", "heads (waves 0..3)", "weights -> registers (once per workgroup; 4-wave experiment only)"]
+    if "-DNDP_EXPERIMENT_FWD_4W" in extra:
+        f8 = ["-", "P0: layer 0, epilogue (L0, g0) [+ heads of the previous tile's g1]", "barriers (six per tile)", "P1: MFMAs (L1, g0) | epilogue (L0, g1)",
+              "P2: MFMAs (L1, g1) | epilogue (L1, g0)", "P3: MFMAs (L2, g0) | epilogue (L1, g1)", "P4: MFMAs (L2, g1) | epilogue (L2, g0)",
+              "P5: epilogue (L2, g1), heads of g0", "-", "-", "weights -> registers (once per workgroup)"]
+    if "-DNDP_EXPERIMENT_FWD_LP" in extra:
+        f8 = ["-", "H1: L1 waves MFMAs (L1, s) | L2 waves heads (s-3)", "barrier", "H2, L1 waves: epilogue (L1, s)",
+              "H2: L1 waves encode s+2 | L2 waves MFMAs (L2, s-1)", "barrier", "H2, L1 waves: layer 0 of s+1", "H1, L2 waves: epilogue (L2, s-2)", "-", "-",
+              "weights -> registers, first encodings (once per workgroup)"]
     tot = sum(buf[12 + i] for i in range(11))
     print(f"fwd8 (bf16 splits): {tot / tiles:.0f} cycles per tile (thread 0 wall)")
     for i, nm in enumerate(f8):
-        print(f"   {nm:40s} {buf[12 + i] / tiles:9.0f}  {100.0 * buf[12 + i] / max(tot, 1):5.1f} %")
+        print(f"   {nm:66s} {buf[12 + i] / tiles:9.0f}  {100.0 * buf[12 + i] / max(tot, 1):5.1f} %")
