@@ -40,8 +40,8 @@ from deformationpyramid_amd.config import Config                 # noqa: E402
 from deformationpyramid_amd.synthetic import surface_pair, synthetic_landmarks, synthetic_pair      # noqa: E402
 
 FP32_PEAK_TFLOPS = 157.3          # MI355X fp32 matrix = vector peak (MI355X_MICROARCH.md)
-BF16_PEAK_TFLOPS = 2500.0         # dense bf16 MFMA peak (same guide)
-SPLIT_PRODUCTS = 6                # bf16 partial products per fp32-equivalent product in the split kernels (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid)
+BF16_PEAK_TFLOPS = 2500.0         # dense 16-bit (bf16 = fp16) MFMA peak (same guide)
+SPLIT_PRODUCTS = 3                # fp16 partial products per fp32-equivalent product in the split kernels (hi.hi, hi.lo, lo.hi); rounds 2-3: six bf16 ones
 FLOP_FWD_PT = 68608
 FLOP_BWD_PT = 135680
 FLOP_NN_PAIR = 8                  # per (source, target) distance evaluation; one pass serves both directions
@@ -106,7 +106,7 @@ def stage_kernels(gemm_mode, nn_mode):
 def roofline_report(model, pairs, B, config):
     """Roofline of the dominant kernel of one engine's tick (HIP events on the launch stream, all slots active at level 0),
     priced against the peak of the pipe that kernel's contractions run on: the fp32 MFMA / vector peak for the bitwise kernels
-    and the nearest-neighbour kernels, the dense bf16 MFMA peak / 6 for the bf16-split level kernels (six bf16 products per
+    and the nearest-neighbour kernels, the dense 16-bit MFMA peak / 3 for the split level kernels (three fp16 products per
     fp32-equivalent product: algorithmic FLOP stay SURVEY 8(d)'s)."""
     prof, eng, preps, active = kernel_profile(model, pairs, B)
     S, T, n = preps[0].S, preps[0].T, preps[0].S + preps[0].K       # n: points through the MLP (landmarks + samples)
@@ -125,7 +125,7 @@ def roofline_report(model, pairs, B, config):
     traffic, src = pmc_traffic(names[dom], active) if config == "A" else (None, None)
     roof = {"bound": "mfma", "kernel": "+".join(names[dom]), "achieved": ach, "peak": peak_of[dom], "unit": "TFLOP/s",
             "frac": ach / peak_of[dom], "traffic": traffic, "traffic_source": src,
-            "peak_is": ("dense bf16 MFMA peak / 6 (six bf16 partial products per fp32-equivalent product)" if split.get(dom)
+            "peak_is": ("dense fp16 MFMA peak / 3 (three fp16 partial products per fp32-equivalent product; rounds 2-3 priced six bf16 ones against / 6)" if split.get(dom)
                         else "fp32 MFMA = fp32 vector peak"),
             "avg_launch_ms": prof[dom], "pairs_per_launch": active, "algorithmic_flop_per_pair_launch": flops[dom]}
     if traffic:                                   # the other ceiling, for the record: HBM bytes/s of the same kernel vs 8 TB/s
@@ -140,8 +140,9 @@ def roofline_report(model, pairs, B, config):
 
 
 ARITH_TEXT = {0: "fp32 MFMA, bitwise the oracle's fma chain",
-              7: "128x128 contractions of the three level kernels as three-way bf16 splits (six partial products) on the bf16 MFMA, "
-                 "fp32 accumulate: fp32-level accuracy (tests/test_split_accuracy.py), not bitwise the chain"}
+              7: "128x128 contractions of the three level kernels as two-way fp16 splits (x = hi + 2^-11 lo, three partial products, gradient "
+                 "operands scaled by a power of two per pair) on the fp16 MFMA, fp32 accumulate: closer to float64 than the fp32 chain "
+                 "(tests/test_split_accuracy.py), not bitwise the chain"}
 NN_TEXT = {0: "one pass, distances on the vector pipe", 1: "latency shape (two passes, 64-query workgroups)",
            2: "one pass, distances on the bf16 matrix pipe + exact re-evaluation (bit-identical results)"}
 
@@ -296,7 +297,7 @@ def main():
     ap.add_argument("--gemm-mode", type=int, default=-1, choices=list(range(-1, 8)),
                     help="-1 (default): the engine's default arithmetic (engine.DEFAULT_GEMM_MODE); 0: level kernels on the fp32 MFMA, "
                          "bitwise the oracle's fma chain; mask 1 forward | 2 bwd1 | 4 bwd2 (7 = all): their 128x128 contractions as "
-                         "three-way bf16 splits on the bf16 MFMA (fp32-level accuracy, not bitwise)")
+                         "two-way fp16 splits on the fp16 MFMA (fp32-level accuracy, not bitwise)")
     ap.add_argument("--nn-mode", type=int, default=-1, choices=[-1, 0, 1, 2],
                     help="-1 (default): the engine chooses (one-pass kernel at throughput sizes -- on the matrix pipe when "
                          "engine.DEFAULT_NN_MATRIX -- latency shape for a few pairs); 0 one-pass on the vector pipe; 1 latency shape; "
@@ -446,7 +447,7 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload, "survey_8d_config": args.config,
-                   "contraction_arithmetic": ARITH_TEXT.get(main_modes[0], f"mask {main_modes[0]} (1 fwd | 2 bwd1 | 4 bwd2) on bf16 splits, the rest on the fp32 MFMA"),
+                   "contraction_arithmetic": ARITH_TEXT.get(main_modes[0], f"mask {main_modes[0]} (1 fwd | 2 bwd1 | 4 bwd2) on fp16 splits, the rest on the fp32 MFMA"),
                    "nn_kernel": NN_TEXT[main_modes[1]], "gemm_mode": main_modes[0], "nn_mode": main_modes[1],
                    "pairs_per_step_per_gpu": NP, "resident_slots_per_gpu": B * args.engines, "engines_per_gpu": args.engines, "parallelism": f"pair-parallel x{n_gpus}, no data-path collective",
                    "backend": ("none" if not use_dist else ("rccl" if backend == "nccl" else backend)),
@@ -472,7 +473,7 @@ def main():
         a_elapsed, a_steps, a_evals, a_last = timed_run(alt_model, args.alt_steps, 1)
         a_eng = alt_model._engines[0]
         a_keys, a_msum = accuracy_sums(a_last)
-        alt = {"name": "split (bf16x3 level kernels + matrix-pipe NN)" if main_modes[0] == 0 else "bitwise (fp32-MFMA level kernels + vector-pipe NN)",
+        alt = {"name": "split (fp16x2 level kernels + matrix-pipe NN)" if main_modes[0] == 0 else "bitwise (fp32-MFMA level kernels + vector-pipe NN)",
                "value": args.alt_steps * NP / a_elapsed, "unit": "pairs/s", "steps": args.alt_steps, "warmup": 1,
                "ms_per_step": 1e3 * a_elapsed / args.alt_steps, "ms_per_iter": 1e3 * a_elapsed / max(a_steps, 1),
                "adam_iters_per_pair": a_steps / (args.alt_steps * NP), "dtype": "f32",

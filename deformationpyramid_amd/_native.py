@@ -58,7 +58,8 @@ class Engine(ctypes.Structure):
                 ("act", ctypes.c_void_p), ("heads", ctypes.c_void_p),
                 ("d2x", ctypes.c_void_p), ("idx_x", ctypes.c_void_p), ("d2y", ctypes.c_void_p),
                 ("idx_y", ctypes.c_void_p), ("adam_tab", ctypes.c_void_p), ("dO", ctypes.c_void_p),
-                ("nn_row", ctypes.c_void_p), ("nn_mode", ctypes.c_int), ("gemm_mode", ctypes.c_int)]
+                ("nn_row", ctypes.c_void_p), ("nn_mode", ctypes.c_int), ("gemm_mode", ctypes.c_int),
+                ("gmax", ctypes.c_void_p)]
 
 
 class WarpJob(ctypes.Structure):

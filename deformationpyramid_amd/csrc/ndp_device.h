@@ -359,7 +359,7 @@ __device__ __forceinline__ float block_sum_256(float v, float *scratch /* >= 256
 // lds_row: NDP_NHMAX floats of LDS private to the calling thread (run-time row offsets live there).
 __device__ __forceinline__ void point_head_bwd(const HeadCfg &hc, const float *heads_row /*global, NDP_HROW*/,
                                                const float *x, const float *g, float g_nr, float *lds_row,
-                                               float *dO_row /*global*/) {
+                                               float *dO_row /*global*/, float *amax = nullptr /* max |dO| of the row */) {
 #pragma unroll
     for (int j = 0; j < NDP_NHMAX; j += 4)
         *reinterpret_cast<float4 *>(lds_row + j) = *reinterpret_cast<const float4 *>(heads_row + j);
@@ -372,5 +372,6 @@ __device__ __forceinline__ void point_head_bwd(const HeadCfg &hc, const float *h
         float4 v = *reinterpret_cast<const float4 *>(lds_row + j);
         v.x *= hc.mlp_scale; v.y *= hc.mlp_scale; v.z *= hc.mlp_scale; v.w *= hc.mlp_scale;
         *reinterpret_cast<float4 *>(dO_row + j) = v;
+        if (amax) *amax = fmaxf(fmaxf(*amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
 }

@@ -1188,6 +1188,7 @@ k_eng_fwd(ndp_engine e, int parity) {
     const int b = blockIdx.y;
     const ndp_pair_state st = e.state[parity * e.B + b];
     if (st.level >= e.m) return;
+    if (e.gmax && blockIdx.x == 0 && threadIdx.x == 0) e.gmax[b] = 0;   // this tick's max |dO| starts from zero (k_eng_loss raises it)
     const ndp_pair_geom gm = e.geom[b];
     LevelJob job;
     job.n = gm.K + gm.S;
@@ -1760,6 +1761,7 @@ k_eng_loss(ndp_engine e, int parity) {
     }
     PT(4);
     // ---- per-point head backward: dO = mlp_scale * dL/d(scaled head outputs); zero rows pad the last tile
+    float amax = 0.f;
     if (p < n) {
         const float *xin = e.pts + ((size_t)b * 2 + st.cur) * e.n_cap * 3 + 3 * p;
         const float xv[3] = {xin[0], xin[1], xin[2]};
@@ -1769,10 +1771,22 @@ k_eng_loss(ndp_engine e, int parity) {
             const float den = (1.0f - nr) * nr;
             g_nr = e.w_reg * ((1.0f / (float)n) * (nr / (den > 1e-12f ? den : 1e-12f)));
         }
-        point_head_bwd(hcl, hrec + (size_t)p * NDP_HROW, xv, g, g_nr, rows + t * NDP_NHMAX, dO_row);
+        point_head_bwd(hcl, hrec + (size_t)p * NDP_HROW, xv, g, g_nr, rows + t * NDP_NHMAX, dO_row, &amax);
     } else if (p < e.n_cap) {
 #pragma unroll
         for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(dO_row + j) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (e.gmax) {                                        // the pair's max |dO|: the split backward scales its gradient operands by it
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
+        float *wm = rows;                                // (every thread is done with its row; one atomic per workgroup, not per wave)
+        __syncthreads();
+        if ((t & 63) == 0) wm[t >> 6] = amax;
+        __syncthreads();
+        if (t == 0) {
+            const float m4 = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
+            if (m4 > 0.f) atomicMax(e.gmax + b, __float_as_uint(m4));      // non-negative floats order like their bit patterns
+        }
     }
     PT(5);
     PT_FLUSH(36);
@@ -2282,6 +2296,10 @@ static int check_engine(const ndp_engine *e, const char *who) {
     if (!e->geom || !e->state || !e->pts || !e->params || !e->gpart || !e->adam_m || !e->adam_v || !e->act ||
         !e->heads || !e->adam_tab || !e->dO) {
         snprintf(g_err, sizeof g_err, "%s: null buffer", who);
+        return NDP_E_INVALID;
+    }
+    if ((e->gemm_mode & 6) && !e->gmax) {
+        snprintf(g_err, sizeof g_err, "%s: the split backward (gemm_mode & 6) needs the gmax buffer", who);
         return NDP_E_INVALID;
     }
     return 0;

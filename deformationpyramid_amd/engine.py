@@ -37,11 +37,11 @@ class OptConfig:
 
 # Arithmetic of the three level kernels / shape of the nearest-neighbour kernel when the caller does not say (ctor argument >
 # environment NDP_GEMM_MODE / NDP_NN_MODE > these defaults):
-#   gemm_mode 7 (default since round 3): (mask 1 forward | 2 bwd1 | 4 bwd2) the 128x128 contractions as three-way bf16 splits on
-#                the bf16 MFMA with fp32 accumulation -- as close to a float64 evaluation as the fp32 chain is
+#   gemm_mode 7 (default since round 3): (mask 1 forward | 2 bwd1 | 4 bwd2) the 128x128 contractions as two-way fp16 splits (hi + 2^-11 lo,
+#                three products) on the fp16 MFMA with fp32 accumulation -- closer to a float64 evaluation than the fp32 chain is
 #                (tests/test_split_accuracy.py), every engine parity test passes at the same tolerances, but not bitwise the chain;
 #             0: the same contractions on the fp32 MFMA, bitwise the oracle's fma chain (Registration(cfg, gemm_mode=0),
-#                bench.py --gemm-mode 0) -- 1/16 of the bf16 matrix rate;
+#                bench.py --gemm-mode 0) -- 1/16 of the 16-bit matrix rate;
 #   nn matrix : the one-pass NN with the distances on the bf16 matrix pipe and exact re-evaluation (bit-identical results).
 DEFAULT_GEMM_MODE = 7
 DEFAULT_NN_MATRIX = True
@@ -112,7 +112,7 @@ class BatchedEngine:
         self.p_stride = (self.P + 63) // 64 * 64
         tiles = self.n_cap // N.TILE
         # workgroups per pair in the level kernels: two 4-wave workgroups per CU (fp32 kernels) or, when all three level kernels run
-        # on bf16 splits, one 8-wave workgroup per CU -- then also half as many gradient partials to write and to fold
+        # on fp16 splits, one 8-wave workgroup per CU -- then also half as many gradient partials to write and to fold
         per_cu = 1 if self.gemm_mode == 7 else 2
         self.G = int(G) if G else max(1, min(tiles, -(-256 * per_cu // B)))
         d = self.device
@@ -142,6 +142,7 @@ class BatchedEngine:
         self.state_nbytes = ctypes.sizeof(N.PairState)
         self.state = torch.zeros(2, B, self.state_nbytes, device=d, dtype=torch.uint8)
         self.geom = torch.zeros(B, 4, device=d, dtype=torch.int32)
+        self.gmax = torch.zeros(B, device=d, dtype=torch.int32)      # max |dO| per pair and tick: the split backward's gradient scale
         self._geom_h = np.zeros((B, 4), dtype=np.int32)
         self._state_h = torch.zeros(B, self.state_nbytes, dtype=torch.uint8).pin_memory()
         self._snap = [torch.zeros(B, self.state_nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]
@@ -162,7 +163,7 @@ class BatchedEngine:
         e.adam_w1, e.adam_b2, e.adam_w2, e.adam_eps = 1 - 0.9, 0.999, 1 - 0.999, 1e-8
         e.nn_mode = self.nn_mode
         for name in ("geom", "state", "pts", "ldmk_t", "tgt", "params", "gpart", "adam_m", "adam_v", "act", "heads",
-                     "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "dO", "nn_row"):
+                     "d2x", "idx_x", "d2y", "idx_y", "adam_tab", "dO", "nn_row", "gmax"):
             setattr(e, name, getattr(self, name).data_ptr())
         self.c_engine = e
 

@@ -91,7 +91,7 @@ def pyramid_fwd(desc: LayerDesc, m, k0, store, x):
 def pyramid_fwd_batch(desc: LayerDesc, m, k0, jobs, device=None, split=False):
     """jobs: [(store [m,p_stride], x [n,3], shift_in [>=3] | None, shift_out [>=3] | None)] -> [x_out [n,3]]: every
     cloud through its whole pyramid in ONE launch per 32 jobs; x_out = pyramid(x - shift_in) + shift_out.
-    split: the engine's bf16-split arithmetic (k_pyramid_fwd8) instead of the fp32 MFMA (bitwise the level chain)."""
+    split: the engine's fp16-split arithmetic (k_pyramid_fwd8) instead of the fp32 MFMA (bitwise the level chain)."""
     if not jobs:
         return []
     arr = (N.WarpJob * len(jobs))()

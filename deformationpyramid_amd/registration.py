@@ -180,7 +180,7 @@ class Registration:
     def __init__(self, config, gemm_mode=None, nn_mode=None, nn_matrix=None):
         """config: the reference's attribute-accessible config (NDP.yaml / LNDP.yaml keys).  gemm_mode / nn_mode (extension, both
         default to the engine's choice, see engine.resolve_modes): arithmetic of the level kernels' 128x128 contractions (0: fp32
-        MFMA, bitwise the oracle's chain; 7: three-way bf16 splits on the bf16 MFMA), a forced shape of the nearest-neighbour kernel
+        MFMA, bitwise the oracle's chain; 7: two-way fp16 splits on the fp16 MFMA), a forced shape of the nearest-neighbour kernel
         (nn_mode) or just the preference for its matrix-pipe variant where the engine picks the throughput shape (nn_matrix)."""
         self.gemm_mode, self.nn_mode, self.nn_matrix = gemm_mode, nn_mode, nn_matrix
         self.tgt_pcd = None
@@ -626,5 +626,5 @@ class Registration:
         for slot, prep in done:
             store = eng.params[slot].clone() if freeze else eng.params[slot]      # [m, p_stride] on device
             jobs.append(prep.warp_job(store))
-        # the final warp runs in the engine's arithmetic: bf16-split contractions with gemm_mode & 1, the fp32 MFMA otherwise
+        # the final warp runs in the engine's arithmetic: fp16-split contractions with gemm_mode & 1, the fp32 MFMA otherwise
         return ops.pyramid_fwd_batch(done[0][1].desc, c.m, c.k0, jobs, device=self._dev(), split=bool(eng.gemm_mode & 1))

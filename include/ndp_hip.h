@@ -248,12 +248,17 @@ typedef struct ndp_engine {
     const float *adam_tab;           /* [iters+1][2]: {neg_step, bc2_sqrt} for t = 1..iters     */
     float *dO;                       /* [B][n_cap][16] mlp_scale * dL/d(head outputs), this tick */
     float *nn_row;                   /* one-pass 1-NN row partials, B x ndp_engine_nn_workspace() floats (NULL if w_cd == 0) */
-    int nn_mode, gemm_mode;          /* gemm_mode 0 (default): level kernels on the fp32 MFMA, bitwise the oracle's fma chain.  OPT-IN
-                                        mask: 1 forward, 2 bwd1, 4 bwd2 with their 128 x 128 contractions as three-way bf16 splits
-                                        on the bf16 MFMA -- fp32-level accuracy, not bitwise the chain (csrc/ndp_*_bf16.inc).
-                                        nn_mode 0: one-pass kernel, distances on the vector pipe; 2: the same on the bf16 matrix pipe with exact re-evaluation
-                                        (bit-identical, needs ndp_engine_nn_matrix_fits(n_cap));  0: one-pass kernel (throughput, many pairs resident); 1: latency shape -- two passes in
-                                        64-query workgroups, S/64 + T/64 of them per pair -- for a handful of resident pairs   */
+    int nn_mode, gemm_mode;          /* gemm_mode 0: level kernels on the fp32 MFMA, bitwise the oracle's fma chain.  Mask 1 forward,
+                                        2 bwd1, 4 bwd2: their 128 x 128 contractions from two-way fp16 splits (hi + 2^-11 lo, three
+                                        products, fp32 accumulate) on the 16-bit MFMA -- fp32-level accuracy, not bitwise the chain
+                                        (csrc/ndp_*_bf16.inc); 7 is what Registration uses by default.
+                                        nn_mode 0: one-pass kernel, distances on the vector pipe; 2: the same on the bf16 matrix pipe
+                                        with exact re-evaluation (bit-identical, needs ndp_engine_nn_matrix_fits(n_cap)); 1: latency
+                                        shape -- two passes in 64-query workgroups, S/64 + T/64 of them per pair -- for a handful of
+                                        resident pairs   */
+    unsigned int *gmax;              /* [B] bit pattern of max |dO| of the pair this tick (zeroed by the forward stage, raised by
+                                        the loss stage): the power-of-two scale that puts the split backward's gradient operands
+                                        into fp16's range.  Required when gemm_mode & 6, else may be NULL.                       */
 } ndp_engine;
 
 /* Floats PER PAIR of the row-partial buffer of the one-pass nearest-neighbour kernel ({d2, idx} per source and

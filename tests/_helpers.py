@@ -51,7 +51,7 @@ def rel_err(a, b):
 
 # The two arithmetic configurations every engine-level parity test runs in (same tolerances for both):
 #   bitwise: level kernels on the fp32 MFMA (the oracle's fma chain) + the vector-pipe nearest-neighbour kernels;
-#   split  : level kernels' 128x128 contractions as three-way bf16 splits on the bf16 MFMA (gemm_mode 7) + the one-pass
+#   split  : level kernels' 128x128 contractions as two-way fp16 splits on the fp16 MFMA (gemm_mode 7) + the one-pass
 #            nearest-neighbour kernel with the distances on the bf16 matrix pipe (nn_mode 2) wherever its table fits LDS.
 ARITH = ("bitwise", "split")
 

@@ -688,7 +688,7 @@ def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name, matrix):
 def test_engine_matches_oracle_at_the_bench_geometry(dev, arith, nn_mode, G):
     """What bench.py times: S = T = 2000 samples, 8 resident pairs of slightly different sizes, 3 iterations x 2 levels, G
     workgroups per pair as the bench's 128-slot engines get them (4 four-wave workgroups with the fp32-MFMA level kernels,
-    2 eight-wave workgroups with the bf16-split ones) -- with each nearest-neighbour kernel (0 one-pass on the vector pipe, 1
+    2 eight-wave workgroups with the split ones) -- with each nearest-neighbour kernel (0 one-pass on the vector pipe, 1
     latency shape, 2 one-pass on the matrix pipe): identical step counts, loss and warped samples within the per-step budget."""
     eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=2000, T=2000, m=2, iters=3, early_stop=False,
                                           w_cd=1.0, trunc=1e9, B=8, G=G, nn_mode=nn_mode, arith=arith)
@@ -713,8 +713,8 @@ def test_engine_nn_shapes_are_bit_identical(dev):
 
 @pytest.mark.parametrize("gemm_mode", [1, 2, 4, 7])
 @pytest.mark.parametrize("tag", ["se3aa", "sim3eu", "sflow"])
-def test_engine_on_bf16_splits_stays_inside_the_parity_budget(dev, tag, gemm_mode):
-    """Opt-in gemm_mode mask (1 forward, 2 bwd1, 4 bwd2: their 128x128 contractions from three-way bf16 splits on the bf16 MFMA): the
+def test_engine_on_fp16_splits_stays_inside_the_parity_budget(dev, tag, gemm_mode):
+    """Opt-in gemm_mode mask (1 forward, 2 bwd1, 4 bwd2: their 128x128 contractions from two-way fp16 splits on the fp16 MFMA): the
     SAME tolerances against the oracle as the default kernels -- loss to 1e-4 relative, warped points to 1e-4, the bulk of the
     parameters after 12 Adam steps -- and, for the forward, activations within 2e-6 of the default forward's (both are ~5e-7 of the
     output scale away from a float64 evaluation)."""

@@ -1,8 +1,8 @@
-"""What justifies `dtype: f32` for the bf16-split level kernels (engine gemm_mode 7).
+"""What justifies `dtype: f32` for the split level kernels (engine gemm_mode 7).
 
 Every kernel of one tick is run on its own (ndp_engine_run_stages) in both arithmetic configurations -- the fp32-MFMA
-kernels, bitwise the oracle's fma chain, and the kernels that form the 128x128 contractions from three-way bf16 splits
-on the bf16 MFMA -- and each output (activations, head outputs, weight / bias gradients, the data gradient dz1) is
+kernels, bitwise the oracle's fma chain, and the kernels that form the 128x128 contractions from two-way fp16 splits
+(x = hi + 2^-11 lo, three products; rounds 2-3: three-way bf16 splits, six products) on the 16-bit MFMA -- and each output (activations, head outputs, weight / bias gradients, the data gradient dz1) is
 compared with a FLOAT64 evaluation of the same kernel on the SAME inputs (the kernel's own input buffers, cast up).
 The split path's maximum error must not exceed 1.5x the fp32 chain's: it is fp32 arithmetic in everything but the
 summation order.  (/root/reference/model/nets.py:111-140 forward; its autograd for the gradients.)
@@ -27,15 +27,22 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None):
-    """One tick of a one-pair engine at `level`, stage by stage; returns every buffer a kernel consumed or produced (CPU, fp32)."""
+def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_cd=1.0, tiny_h0=False):
+    """One tick of a one-pair engine at `level`, stage by stage; returns every buffer a kernel consumed or produced (CPU, fp32).
+    w_cd: weight of the loss (every gradient scales with it).  tiny_h0: layer 0 of the level = (W0 = 0, b0 = 1e-9), i.e. every
+    h0 is positive and below fp16's smallest subnormal (and h1 = relu(1e-9 W1 1 + b1) has such elements too)."""
     from deformationpyramid_amd.engine import BatchedEngine, OptConfig
     m = level + 1
     pyr = seeded_pyramid(11, m=m, **VARIANTS[tag])
     for lvl in range(m):
         scale_heads(pyr, lvl, head_scale)                   # head outputs of O(0.01): rotations / translations that matter
     d = pyr.descs[0]
-    cfg = OptConfig(m=m, iters=2, early_stop=False)
+    if tiny_h0:
+        with torch.no_grad():
+            pyr.store[level, d.off_W(0):d.off_W(0) + d.width * 6] = 0.0
+            pyr.store[level, d.off_b(0):d.off_b(0) + d.width] = 1e-9
+            pyr.store[level, d.off_b(1):d.off_b(1) + d.width] = 0.0
+    cfg = OptConfig(m=m, iters=2, early_stop=False, w_cd=w_cd)
     eng = BatchedEngine(d, cfg, 1, n_cap=S, t_cap=T, device=dev, gemm_mode=gemm_mode, nn_mode=1, G=G)
     g = torch.Generator().manual_seed(3)
     src = (torch.rand(S, 3, generator=g) - 0.5).contiguous()
@@ -154,3 +161,40 @@ def test_split_kernels_are_as_close_to_float64_as_the_fp32_chain(dev, tag, level
         large = r["elements"] >= 10000
         assert r["split_rms"] <= (RATIO if large else 3.0) * r["chain_rms"] + 1e-9, (k, "rms ratio", r["split_rms"] / max(r["chain_rms"], 1e-30), report)
         assert r["split_max"] <= (2.0 if large else 3.0) * r["chain_max"] + 2e-8, (k, "max ratio", r["split_max"] / max(r["chain_max"], 1e-30), report)
+
+
+GRAD_TENSORS = ("dW2", "db2", "dz1", "dW1", "db1", "dW0", "db0")
+
+
+@pytest.mark.parametrize("w_cd", [1e-7, 3e4])
+def test_gradient_scale_keeps_the_split_backward_exact_over_the_range_of_gradients(dev, w_cd):
+    """The split backward multiplies its gradient operands by S = 2^k (k from the pair's max |dO| of the tick, left in e.gmax by
+    k_eng_loss) so that they sit in fp16's range, and the results by 1 / S.  With the loss weighted 1e-7 (|dO| ~ 1e-11: every
+    unscaled fp16 part would be zero) and 3e4 (|dO| ~ 10: an unscaled hi x 2^11 lo would be at fp16's ceiling) the gradient tensors
+    are as close to float64 as the fp32 chain's, by the bars of the test above."""
+    e_chain = _errors(_run_tick_by_stages(dev, "se3aa", 0, 2000, 2000, 1, 20.0, G=2, w_cd=w_cd))
+    e_split = _errors(_run_tick_by_stages(dev, "se3aa", 7, 2000, 2000, 1, 20.0, G=2, w_cd=w_cd))
+    for k in GRAD_TENSORS:
+        (cm, cr, n), (sm, sr, _) = e_chain[k], e_split[k]
+        large = n >= 10000
+        assert sm < 5e-6 and cm < 5e-6, (k, sm, cm)
+        assert sr <= (RATIO if large else 3.0) * cr + 1e-9, (k, "rms ratio", sr / max(cr, 1e-30))
+        assert sm <= (2.0 if large else 3.0) * cm + 2e-8, (k, "max ratio", sm / max(cm, 1e-30))
+
+
+def test_relu_masks_of_the_split_backward_see_activations_below_fp16s_range(dev):
+    """The ReLU masks of the split backward are read from the hi plane of the activation.  With h0 = 1e-9 everywhere (and elements
+    of h1 of the same size) a plain fp16 conversion would make every hi zero and mask the whole gradient away; the split keeps
+    hi > 0 exactly where the activation is.  dz1 (masked by h1), dW0 / db0 (dz0 masked by h0) against float64 with the true masks."""
+    r = _run_tick_by_stages(dev, "se3aa", 7, 2000, 2000, 0, 20.0, G=2, tiny_h0=True)
+    h0, h1 = r["act_fwd"][0, :2000], r["act_fwd"][1, :2000]
+    assert float(h0.max()) < 3e-8 and float(h0.min()) > 0.0                       # below fp16's smallest subnormal, all positive
+    assert int(((h1 > 0) & (h1 < 3e-8)).sum()) > 1000
+    e = _errors(r)
+    ref = _f64_reference(r)
+    assert float(ref["db0"].abs().max()) > 0 and float(ref["dz1"].abs().max()) > 0
+    for k in ("dz1", "dW0", "db0", "db1"):
+        assert e[k][0] < 5e-6, (k, e[k])
+    # dW1 = dz1^T h0 is built from the VALUES of those activations: a two-way fp16 split carries an absolute error of up to
+    # 2^-36 = 1.5e-11 per operand element (half a subnormal step of lo, times 2^-11) -- nothing beside O(1) activations, 1.5 % of 1e-9
+    assert e["dW1"][0] < 0.03, e["dW1"]

@@ -125,6 +125,6 @@ elif eng.gemm_mode & 1:
               "H2: L1 waves encode s+2 | L2 waves MFMAs (L2, s-1)", "barrier", "H2, L1 waves: layer 0 of s+1", "H1, L2 waves: epilogue (L2, s-2)", "-", "-",
               "weights -> registers, first encodings (once per workgroup)"]
     tot = sum(buf[12 + i] for i in range(11))
-    print(f"fwd8 (bf16 splits): {tot / tiles:.0f} cycles per tile (thread 0 wall)")
+    print(f"fwd8 (fp16 splits): {tot / tiles:.0f} cycles per tile (thread 0 wall)")
     for i, nm in enumerate(f8):
         print(f"   {nm:66s} {buf[12 + i] / tiles:9.0f}  {100.0 * buf[12 + i] / max(tot, 1):5.1f} %")

@@ -1,4 +1,4 @@
-"""Final all-point warp (registration.py:253-258) of 32 clouds x 8192 points x 9 levels: fp32-MFMA kernel vs the bf16-split kernel.
+"""Final all-point warp (registration.py:253-258) of 32 clouds x 8192 points x 9 levels: fp32-MFMA kernel vs the fp16-split kernel.
     python tools/warp_bench.py [n_jobs] [points]"""
 import os, sys
 import torch
@@ -25,4 +25,4 @@ for split in (False, True):
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 10
     fl = 617472.0 * n * nj
-    print(f"{'bf16-split k_pyramid_fwd8' if split else 'fp32-MFMA  k_pyramid_fwd '}: {ms:.3f} ms per launch of {nj} clouds, {1e3 * ms / nj:.1f} us per cloud, {fl / ms / 1e9:.1f} TFLOP/s")
+    print(f"{'fp16-split k_pyramid_fwd8' if split else 'fp32-MFMA  k_pyramid_fwd '}: {ms:.3f} ms per launch of {nj} clouds, {1e3 * ms / nj:.1f} us per cloud, {fl / ms / 1e9:.1f} TFLOP/s")
