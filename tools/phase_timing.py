@@ -91,7 +91,7 @@ if eng.nn_mode == 2:
         print(f"   {nm:58s} {buf[64 + i] / wgs:9.0f}  {100.0 * buf[64 + i] / max(tot, 1):5.1f} %")
 if eng.gemm_mode & 4:
     nm2 = ["top barrier (incl. wait for the requested rows)", "h1 split + h2 tile + dO rows -> LDS", "barrier", "dz2 chain (VALU) + split -> planes", "barrier",
-           "dWh (fp32 MFMA 16x16x4)", "wgrad (48 MFMA 32x32x16)", "dgrad (96 MFMA 16x16x32) + mask + dz1 store", "tail: dW store, bias sums (once)"]
+           "dWh (fp32 MFMA 16x16x4)", "wgrad (24 MFMA 32x32x16)", "dgrad (48 MFMA 16x16x32) + mask + dz1 store", "tail: dW store, bias sums (once)"]
     tot = sum(buf[i] for i in range(12))
     print(f"bwd2_8: {tot / tiles:.0f} cycles per tile (thread 0 wall)")
     for i, nm in enumerate(nm2):
