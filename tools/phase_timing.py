@@ -31,7 +31,9 @@ eng = model._engine(B, preps[0])
 eng.load_jobs([p.load_job(b) for b, p in enumerate(preps)][:16])
 for i in range(16, B, 16):
     eng.load_jobs([p.load_job(b) for b, p in enumerate(preps)][i:i + 16])
-FWD_ONLY = os.environ.get("NDP_PT_FWD_ONLY") == "1"      # timing-only variants with wrong results: the forward stage alone, state untouched
+# timing-only variants with wrong results: ONE stage alone, over and over, the pair states untouched (NDP_PT_STAGE = 0 forward .. 4 bwd1)
+STAGE = int(os.environ.get("NDP_PT_STAGE", "0" if os.environ.get("NDP_PT_FWD_ONLY") == "1" else "-1"))
+FWD_ONLY = STAGE >= 0
 if not FWD_ONLY:
     eng.run_ticks(4)
 torch.cuda.synchronize()
@@ -39,16 +41,17 @@ L = N.lib()
 buf = (ctypes.c_ulonglong * 96)()
 L.ndp_debug_phase_read(buf, 1)
 if FWD_ONLY:
-    eng.run_stages(0, 0)
+    eng.run_stages(0, STAGE)                                 # the stages before it once, with whatever this build computes
     torch.cuda.synchronize()
     L.ndp_debug_phase_read(buf, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(ticks):
-        eng.run_stages(0, 0)
+        eng.run_stages(STAGE, STAGE)
     e1.record()
     torch.cuda.synchronize()
-    ms = [e0.elapsed_time(e1), 0, 0, 0, 0, 0]
+    ms = [0] * 6
+    ms[STAGE] = e0.elapsed_time(e1)
 else:
     ms = eng.run_ticks_timed(ticks)
 L.ndp_debug_phase_read(buf, 1)
