@@ -1841,11 +1841,19 @@ k_eng_bwd1(ndp_engine e, int parity) {
 
 #include "ndp_bwd_bf16.inc"
 
-// fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state).  A thread owns FOUR consecutive
-// parameters (p_stride is a multiple of 4: every row starts 16-byte aligned): 16-byte loads and stores, the same per-element
-// arithmetic in the same order as one parameter per thread.
-__device__ __forceinline__ void eng_update_one(const ndp_engine &e, const ndp_pair_state &ns, int b, int i, int pc, float *m, float *v) {
-    if (i >= pc) {                                       // level 0 has no gate row: nothing to step, keep moments clean
+// fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state).
+// (Four parameters per thread on 16-byte accesses: no faster at 128 pairs -- 0.0305 against 0.0315 ms -- and TWICE as slow at batch 1,
+//  where the G = 32 partials are folded by a quarter of the threads: 0.023 against 0.012 ms.  One parameter per thread it stays.)
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_update(ndp_engine e, int parity) {
+    const int b = blockIdx.y;
+    const ndp_pair_state ns = e.state[(size_t)(parity ^ 1) * e.B + b];      // written by k_eng_bwd this tick
+    if (ns.decision == NDP_DEC_IDLE) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const ndp_layer_desc dl = desc_at_level(e.desc, ns.step_level);
+    if (i >= e.P) return;
+    float *m = e.adam_m + (size_t)b * e.p_stride, *v = e.adam_v + (size_t)b * e.p_stride;
+    if (i >= ndp_param_count(&dl)) {                     // level 0 has no gate row: nothing to step, keep moments clean
         if (ns.decision != NDP_DEC_STEP) { m[i] = 0.f; v[i] = 0.f; }
         return;
     }
@@ -1860,41 +1868,6 @@ __device__ __forceinline__ void eng_update_one(const ndp_engine &e, const ndp_pa
         p[i] = pi; m[i] = mi; v[i] = vi;
     }
     if (ns.decision != NDP_DEC_STEP) { m[i] = 0.f; v[i] = 0.f; }             // registration.py:176
-}
-
-extern "C" __global__ void __launch_bounds__(256)
-k_eng_update(ndp_engine e, int parity) {
-    const int b = blockIdx.y;
-    const ndp_pair_state ns = e.state[(size_t)(parity ^ 1) * e.B + b];      // written by k_eng_bwd this tick
-    if (ns.decision == NDP_DEC_IDLE) return;
-    const int i = 4 * (blockIdx.x * 256 + threadIdx.x);
-    if (i >= e.P) return;
-    const ndp_layer_desc dl = desc_at_level(e.desc, ns.step_level);
-    const int pc = ndp_param_count(&dl);
-    float *m = e.adam_m + (size_t)b * e.p_stride, *v = e.adam_v + (size_t)b * e.p_stride;
-    if (i + 3 < pc && i + 3 < e.P) {                     // four live parameters: the vector path
-        float4 mi = *reinterpret_cast<float4 *>(m + i), vi = *reinterpret_cast<float4 *>(v + i);
-        if (ns.decision != NDP_DEC_ADVANCE) {
-            const float *gp = e.gpart + (size_t)b * e.G * e.p_stride;
-            float4 g = *reinterpret_cast<const float4 *>(gp + i);
-            for (int k = 1; k < e.G; ++k) {
-                const float4 gk = *reinterpret_cast<const float4 *>(gp + (size_t)k * e.p_stride + i);
-                g.x += gk.x; g.y += gk.y; g.z += gk.z; g.w += gk.w;
-            }
-            float *p = e.params + ((size_t)b * e.m + ns.step_level) * e.p_stride;
-            float4 pi = *reinterpret_cast<float4 *>(p + i);
-            const float ns_ = e.adam_tab[2 * ns.step_t], bc = e.adam_tab[2 * ns.step_t + 1];
-            adam_update(pi.x, g.x, mi.x, vi.x, e.adam_w1, e.adam_b2, e.adam_w2, ns_, bc, e.adam_eps);
-            adam_update(pi.y, g.y, mi.y, vi.y, e.adam_w1, e.adam_b2, e.adam_w2, ns_, bc, e.adam_eps);
-            adam_update(pi.z, g.z, mi.z, vi.z, e.adam_w1, e.adam_b2, e.adam_w2, ns_, bc, e.adam_eps);
-            adam_update(pi.w, g.w, mi.w, vi.w, e.adam_w1, e.adam_b2, e.adam_w2, ns_, bc, e.adam_eps);
-            *reinterpret_cast<float4 *>(p + i) = pi;
-        }
-        if (ns.decision != NDP_DEC_STEP) mi = vi = make_float4(0.f, 0.f, 0.f, 0.f);      // registration.py:176
-        *reinterpret_cast<float4 *>(m + i) = mi; *reinterpret_cast<float4 *>(v + i) = vi;
-        return;
-    }
-    for (int k = i; k < i + 4 && k < e.P; ++k) eng_update_one(e, ns, b, k, pc, m, v);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2513,7 +2486,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (e->gemm_mode & 4) if (int rc = set_smem((const void *)k_eng_bwd2_8, kSmemBwd8Bytes)) return rc;
     const dim3 g_nn(nn1_row_chunks(e->t_cap), e->B);
     const dim3 g_nn_lat(e->n_cap / 64 + e->t_cap / 64, e->B);
-    const dim3 g_upd((e->P + 1023) / 1024, e->B);
+    const dim3 g_upd((e->P + 255) / 256, e->B);
     const dim3 g_loss((e->n_cap + 255) / 256 + 1, e->B);   // + 1: the loss / decision workgroup
     for (int k = 0; k < n_ticks; ++k) {
         const int parity = (tick0 + k) & 1;
