@@ -27,7 +27,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_cd=1.0, tiny_h0=False):
+def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_cd=1.0, tiny_h0=False, b1=None):
     """One tick of a one-pair engine at `level`, stage by stage; returns every buffer a kernel consumed or produced (CPU, fp32).
     w_cd: weight of the loss (every gradient scales with it).  tiny_h0: layer 0 of the level = (W0 = 0, b0 = 1e-9), i.e. every
     h0 is positive and below fp16's smallest subnormal (and h1 = relu(1e-9 W1 1 + b1) has such elements too)."""
@@ -42,6 +42,9 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
             pyr.store[level, d.off_W(0):d.off_W(0) + d.width * 6] = 0.0
             pyr.store[level, d.off_b(0):d.off_b(0) + d.width] = 1e-9
             pyr.store[level, d.off_b(1):d.off_b(1) + d.width] = 0.0
+    if b1 is not None:
+        with torch.no_grad():
+            pyr.store[level, d.off_b(1):d.off_b(1) + d.width] = b1
     cfg = OptConfig(m=m, iters=2, early_stop=False, w_cd=w_cd)
     eng = BatchedEngine(d, cfg, 1, n_cap=S, t_cap=T, device=dev, gemm_mode=gemm_mode, nn_mode=1, G=G)
     g = torch.Generator().manual_seed(3)
@@ -198,3 +201,14 @@ def test_relu_masks_of_the_split_backward_see_activations_below_fp16s_range(dev)
     # dW1 = dz1^T h0 is built from the VALUES of those activations: a two-way fp16 split carries an absolute error of up to
     # 2^-36 = 1.5e-11 per operand element (half a subnormal step of lo, times 2^-11) -- nothing beside O(1) activations, 1.5 % of 1e-9
     assert e["dW1"][0] < 0.03, e["dW1"]
+
+
+def test_activations_beyond_fp16s_range_saturate(dev):
+    """fp16 ends at 65504.  An activation beyond it enters the next contraction as 65504 (the fp32 copy the backward reads keeps its
+    value), a weight likewise: the results are then no longer the fp32 chain's, but they stay finite -- no inf, no NaN anywhere in
+    the tick.  (This network's activations are O(1): its inputs are sines and cosines, its weights O(0.1).)"""
+    r = _run_tick_by_stages(dev, "se3aa", 7, 2000, 2000, 0, 20.0, G=2, b1=1.0e5)
+    assert float(r["act_fwd"][1, :2000].min()) > 65504.0                         # every h1 is out of range
+    for k in ("act_fwd", "heads", "dO", "dz1"):
+        assert bool(torch.isfinite(r[k][..., :2000, :] if r[k].dim() == 3 else r[k][:2000]).all()), k
+    assert bool(torch.isfinite(r["g_all"]).all())
