@@ -1212,6 +1212,9 @@ k_eng_fwd(ndp_engine e, int parity) {
 }
 
 #include "ndp_fwd_bf16.inc"
+#if defined(NDP_EXPERIMENT_FWD_2X4)
+#include "../../tools/experiments/ndp_fwd_2x4.inc"
+#endif
 #if defined(NDP_EXPERIMENT_FWD_AS) || defined(NDP_EXPERIMENT_FWD_AS16) || defined(NDP_EXPERIMENT_FWD_4W) || defined(NDP_EXPERIMENT_FWD_LP)   /* tools/experiments: other shapes of the bf16 forward */
 #include "../../tools/experiments/ndp_fwd_as.inc"
 #include "../../tools/experiments/ndp_fwd_as16.inc"
@@ -2473,7 +2476,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     const bool fwd_as = engine_fwd_as(e);
     (void)fwd_as;
-#if defined(NDP_EXPERIMENT_FWD_LP)
+#if defined(NDP_EXPERIMENT_FWD_2X4)
+    if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd2x4, kSmemFwd2x4Bytes)) return rc;
+#elif defined(NDP_EXPERIMENT_FWD_LP)
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd_lp, kSmemFwdLpBytes)) return rc;
 #elif defined(NDP_EXPERIMENT_FWD_4W)
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd4w, kSmemFwd4wBytes)) return rc;
@@ -2497,7 +2502,10 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         NDP_EV();
         if (!NDP_ST(0)) {}
         else if (e->gemm_mode & 1) {
-#if defined(NDP_EXPERIMENT_FWD_LP)
+#if defined(NDP_EXPERIMENT_FWD_2X4)
+            if (true) hipLaunchKernelGGL(k_eng_fwd2x4, dim3(2 * g_fwd8.x, e->B), dim3(256), kSmemFwd2x4Bytes, s, *e, parity);
+            else
+#elif defined(NDP_EXPERIMENT_FWD_LP)
             if (true) hipLaunchKernelGGL(k_eng_fwd_lp, g_fwd8, dim3(512), kSmemFwdLpBytes, s, *e, parity);
             else
 #elif defined(NDP_EXPERIMENT_FWD_4W)
