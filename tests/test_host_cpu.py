@@ -349,3 +349,47 @@ def test_stale_library_is_detected_by_its_build_id(tmp_path):
     L = N.lib()
     sizes = (ctypes.c_int * 6)()
     assert L.ndp_abi_sizes(sizes) == 0 and sizes[3] == ctypes.sizeof(N.Engine) and sizes[2] == ctypes.sizeof(N.PairState)
+
+
+def test_two_way_fp16_split_model_is_as_exact_as_fp32():
+    """The arithmetic of the split level kernels (csrc/ndp_fwd_bf16.inc), modelled in numpy: x = hi + 2^-11 lo with hi = fp16(x),
+    lo = fp16(2^11 (x - hi)) represents x to within 2^-23 |x| -- one fp32 ulp -- and a 128-term contraction from the
+    three products hi.hi + 2^-11 (hi.lo + lo.hi), accumulated in fp32, is at least as close to float64 as the fp32 chain.  An
+    UNSCALED lo (fp16(x - hi)) is not: the remainder of a weight of 0.09 is a subnormal."""
+    rng = np.random.default_rng(5)
+
+    def split(x, scale=2048.0):
+        hi = x.astype(np.float16).astype(np.float32)
+        lo = ((x - hi).astype(np.float32) * np.float32(scale)).astype(np.float16).astype(np.float32)
+        return hi, lo
+
+    def mm32(a, b):                                   # exact products, fp32 accumulation in k-steps of 32 (the MFMA's)
+        acc = np.zeros((a.shape[0], b.shape[1]), np.float32)
+        for k0 in range(0, a.shape[1], 32):
+            acc = (acc + (a[:, k0:k0 + 32].astype(np.float64) @ b[k0:k0 + 32].astype(np.float64)).astype(np.float32)).astype(np.float32)
+        return acc
+
+    W = rng.uniform(-0.088, 0.088, (128, 128)).astype(np.float32)
+    H = np.maximum(rng.normal(0, 1, (128, 512)), 0).astype(np.float32)
+    for x in (W, H):
+        hi, lo = split(x)
+        rep = hi.astype(np.float64) + lo.astype(np.float64) / 2048.0
+        big = np.abs(x) >= 2.0 ** -11
+        assert np.max(np.abs(rep - x)[big] / np.abs(x[big])) <= 2.0 ** -23        # one fp32 ulp at worst (fp32's own rounding: half of that)
+        if (~big).any():
+            assert np.max(np.abs(rep - x)[~big]) <= 2.0 ** -34                    # absolute floor for small values (subnormal steps of lo / 2^11)
+    ref = W.astype(np.float64) @ H.astype(np.float64)
+    chain = np.zeros_like(ref, dtype=np.float32)
+    for k in range(128):
+        chain = (chain + (W[:, k:k + 1] * H[k:k + 1, :]).astype(np.float32)).astype(np.float32)
+
+    def three_products(scale):
+        wh, wl = split(W, scale)
+        hh, hl = split(H, scale)
+        return (mm32(wh, hh) + (mm32(wh, hl) + mm32(wl, hh)).astype(np.float32) / np.float32(scale)).astype(np.float32)
+
+    def rms(y):
+        return float(np.sqrt(np.mean((y - ref) ** 2)))
+
+    assert rms(three_products(2048.0)) <= rms(chain)
+    assert rms(three_products(1.0)) > 1.5 * rms(chain)
