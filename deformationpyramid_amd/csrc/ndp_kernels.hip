@@ -2432,7 +2432,7 @@ extern "C" int ndp_adam_step(float *params, const float *grads, float *m, float 
 }
 
 // workgroups per pair of the bf16 level kernels, and whether the forward among them is the activation-stationary one
-static int engine_g8(const ndp_engine *e) { return e->gemm_mode == 7 ? e->G : (e->G > 1 ? e->G / 2 : 1); }
+static int engine_g8(const ndp_engine *e) { return (e->gemm_mode & 7) == 7 ? e->G : (e->G > 1 ? e->G / 2 : 1); }
 static bool engine_fwd_as(const ndp_engine *e) {
 #if defined(NDP_EXPERIMENT_FWD_AS) || defined(NDP_EXPERIMENT_FWD_AS16)
     return (e->gemm_mode & 1) && (e->n_cap / NDP_TILE) >= 4 * engine_g8(e);
@@ -2472,7 +2472,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
     // partials per pair); in a mixed configuration they take half the fp32 grid and zero the partials they do not write.
     const dim3 g_fwd8(engine_g8(e), e->B);
-    if (e->gemm_mode < 0 || e->gemm_mode > 7) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on bf16 splits");
+    if (e->gemm_mode < 0 || e->gemm_mode > 15) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0)");
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     const bool fwd_as = engine_fwd_as(e);
     (void)fwd_as;

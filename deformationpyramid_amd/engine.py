@@ -55,8 +55,9 @@ def resolve_modes(B, n_cap, t_cap, gemm_mode=None, nn_mode=None, nn_matrix=None)
     if gemm_mode is None:
         gemm_mode = int(os.environ.get("NDP_GEMM_MODE", DEFAULT_GEMM_MODE))
     gemm_mode = int(gemm_mode)
-    if not 0 <= gemm_mode <= 7:
-        raise N.NdpError(f"gemm_mode must be a mask of 1 (forward) | 2 (bwd1) | 4 (bwd2), got {gemm_mode}")
+    if not 0 <= gemm_mode <= 15:
+        raise N.NdpError(f"gemm_mode must be a mask of 1 (forward) | 2 (bwd1) | 4 (bwd2) [| 8: the split forward also stores h0, "
+                         f"which bwd1 on the splits recomputes -- tests], got {gemm_mode}")
     fits2 = bool(lib.ndp_engine_nn_matrix_fits(n_cap))
     fits0 = bool(lib.ndp_engine_nn_onepass_fits(n_cap))
     if nn_mode is not None:
@@ -113,7 +114,7 @@ class BatchedEngine:
         tiles = self.n_cap // N.TILE
         # workgroups per pair in the level kernels: two 4-wave workgroups per CU (fp32 kernels) or, when all three level kernels run
         # on fp16 splits, one 8-wave workgroup per CU -- then also half as many gradient partials to write and to fold
-        per_cu = 1 if self.gemm_mode == 7 else 2
+        per_cu = 1 if (self.gemm_mode & 7) == 7 else 2
         self.G = int(G) if G else max(1, min(tiles, -(-256 * per_cu // B)))
         d = self.device
         f32 = dict(device=d, dtype=torch.float32)

@@ -251,7 +251,9 @@ typedef struct ndp_engine {
     int nn_mode, gemm_mode;          /* gemm_mode 0: level kernels on the fp32 MFMA, bitwise the oracle's fma chain.  Mask 1 forward,
                                         2 bwd1, 4 bwd2: their 128 x 128 contractions from two-way fp16 splits (hi + 2^-11 lo, three
                                         products, fp32 accumulate) on the 16-bit MFMA -- fp32-level accuracy, not bitwise the chain
-                                        (csrc/ndp_*_bf16.inc); 7 is what Registration uses by default.
+                                        (csrc/ndp_*_bf16.inc); 7 is what Registration uses by default.  With 1 | 2 the forward does
+                                        not store h0 (act[b][0] is left untouched): bwd1 recomputes it from the saved encoding with
+                                        the forward's own two MFMAs; bit 8 makes the forward store it all the same (tests).
                                         nn_mode 0: one-pass kernel, distances on the vector pipe; 2: the same on the bf16 matrix pipe
                                         with exact re-evaluation (bit-identical, needs ndp_engine_nn_matrix_fits(n_cap)); 1: latency
                                         shape -- two passes in 64-query workgroups, S/64 + T/64 of them per pair -- for a handful of

@@ -27,7 +27,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_cd=1.0, tiny_h0=False, b1=None):
+def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_cd=1.0, tiny_h0=False, b1=None, keep_h0=True):
     """One tick of a one-pair engine at `level`, stage by stage; returns every buffer a kernel consumed or produced (CPU, fp32).
     w_cd: weight of the loss (every gradient scales with it).  tiny_h0: layer 0 of the level = (W0 = 0, b0 = 1e-9), i.e. every
     h0 is positive and below fp16's smallest subnormal (and h1 = relu(1e-9 W1 1 + b1) has such elements too)."""
@@ -46,7 +46,9 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
         with torch.no_grad():
             pyr.store[level, d.off_b(1):d.off_b(1) + d.width] = b1
     cfg = OptConfig(m=m, iters=2, early_stop=False, w_cd=w_cd)
-    eng = BatchedEngine(d, cfg, 1, n_cap=S, t_cap=T, device=dev, gemm_mode=gemm_mode, nn_mode=1, G=G)
+    # gemm_mode 7: the split forward does not store h0 (bwd1 recomputes it); bit 8 makes it store h0 for the comparisons below --
+    # test_h0_is_recomputed... pins that the bit changes nothing else
+    eng = BatchedEngine(d, cfg, 1, n_cap=S, t_cap=T, device=dev, gemm_mode=(15 if gemm_mode == 7 and keep_h0 else gemm_mode), nn_mode=1, G=G)
     g = torch.Generator().manual_seed(3)
     src = (torch.rand(S, 3, generator=g) - 0.5).contiguous()
     tgt = ((torch.rand(T, 3, generator=g) - 0.5) * 1.05 + 0.02).contiguous()
@@ -162,6 +164,8 @@ def test_split_kernels_are_as_close_to_float64_as_the_fp32_chain(dev, tag, level
         # relative to the tensor's own scale both sit at a few fp32 ulps of a 128- (or 2000-) term sum
         assert r["chain_max"] < 5e-6 and r["split_max"] < 5e-6, (k, r)
         large = r["elements"] >= 10000
+        if r["elements"] < 16:
+            continue                                  # dbh: three to seven plain fp32 sums in both kernels -- a ratio of two such errors is noise
         assert r["split_rms"] <= (RATIO if large else 3.0) * r["chain_rms"] + 1e-9, (k, "rms ratio", r["split_rms"] / max(r["chain_rms"], 1e-30), report)
         assert r["split_max"] <= (2.0 if large else 3.0) * r["chain_max"] + 2e-8, (k, "max ratio", r["split_max"] / max(r["chain_max"], 1e-30), report)
 
@@ -212,3 +216,16 @@ def test_activations_beyond_fp16s_range_saturate(dev):
     for k in ("act_fwd", "heads", "dO", "dz1"):
         assert bool(torch.isfinite(r[k][..., :2000, :] if r[k].dim() == 3 else r[k][:2000]).all()), k
     assert bool(torch.isfinite(r["g_all"]).all())
+
+
+def test_h0_is_recomputed_by_the_split_backward_not_read_back(dev):
+    """With forward and bwd1 on the splits the forward does not store h0 -- act[0] keeps whatever was there -- and bwd1 recomputes it
+    from the saved encoding with the forward's own two MFMAs per point group: every gradient and dz1 are BITWISE what they are when
+    the forward is told to store h0 as well (gemm_mode bit 8, which bwd1 ignores), and the h0 that bit stores is what layer 1 saw."""
+    a = _run_tick_by_stages(dev, "se3aa", 7, 2000, 2000, 1, 20.0, G=2, keep_h0=True)
+    b = _run_tick_by_stages(dev, "se3aa", 7, 2000, 2000, 1, 20.0, G=2, keep_h0=False)
+    assert bool(torch.isnan(b["act_fwd"][0]).all())                               # never written (the test pre-fills act with NaN)
+    assert bool(torch.isfinite(a["act_fwd"][0, :2000]).all())
+    for k in ("heads", "dO", "dz1", "g_bwd2", "g_all"):
+        assert torch.equal(a[k], b[k]), k
+    assert torch.equal(a["act_fwd"][1:], b["act_fwd"][1:])

@@ -117,7 +117,7 @@ if getattr(eng, 'fwd_as', False):
     for i, nm in enumerate(f9):
         print(f"   {nm:48s} {buf[12 + i] / tiles:9.0f}  {100.0 * buf[12 + i] / max(tot, 1):5.1f} %")
 elif eng.gemm_mode & 1:
-    f8 = ["-", "layer 0 (VALU) + split + planes + h0 store", "barrier", "-", "layer 1 MFMA + epilogue", "barrier", "-",
+    f8 = ["-", "layer 0 (two MFMAs per group) + split + planes", "barrier", "-", "layer 1 MFMA + epilogue", "barrier", "-",
           "layer 2 MFMA + epilogue", "barrier", "heads (waves 0..3)", "weights -> registers (once per workgroup; 4-wave experiment only)"]
     if "-DNDP_EXPERIMENT_FWD_4W" in extra:
         f8 = ["-", "P0: layer 0, epilogue (L0, g0) [+ heads of the previous tile's g1]", "barriers (six per tile)", "P1: MFMAs (L1, g0) | epilogue (L0, g1)",
