@@ -1215,6 +1215,9 @@ k_eng_fwd(ndp_engine e, int parity) {
 #if defined(NDP_EXPERIMENT_FWD_2X4)
 #include "../../tools/experiments/ndp_fwd_2x4.inc"
 #endif
+#if defined(NDP_EXPERIMENT_FWD_AS2)
+#include "../../tools/experiments/ndp_fwd_as2.inc"
+#endif
 #if defined(NDP_EXPERIMENT_FWD_AS) || defined(NDP_EXPERIMENT_FWD_AS16) || defined(NDP_EXPERIMENT_FWD_4W) || defined(NDP_EXPERIMENT_FWD_LP)   /* tools/experiments: other shapes of the bf16 forward */
 #include "../../tools/experiments/ndp_fwd_as.inc"
 #include "../../tools/experiments/ndp_fwd_as16.inc"
@@ -2476,7 +2479,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     const bool fwd_as = engine_fwd_as(e);
     (void)fwd_as;
-#if defined(NDP_EXPERIMENT_FWD_2X4)
+#if defined(NDP_EXPERIMENT_FWD_AS2)
+    if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd_as2, kSmemFwdAs2Bytes)) return rc;
+#elif defined(NDP_EXPERIMENT_FWD_2X4)
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd2x4, kSmemFwd2x4Bytes)) return rc;
 #elif defined(NDP_EXPERIMENT_FWD_LP)
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd_lp, kSmemFwdLpBytes)) return rc;
@@ -2502,7 +2507,10 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         NDP_EV();
         if (!NDP_ST(0)) {}
         else if (e->gemm_mode & 1) {
-#if defined(NDP_EXPERIMENT_FWD_2X4)
+#if defined(NDP_EXPERIMENT_FWD_AS2)
+            if (true) hipLaunchKernelGGL(k_eng_fwd_as2, g_fwd8, dim3(512), kSmemFwdAs2Bytes, s, *e, parity);
+            else
+#elif defined(NDP_EXPERIMENT_FWD_2X4)
             if (true) hipLaunchKernelGGL(k_eng_fwd2x4, dim3(2 * g_fwd8.x, e->B), dim3(256), kSmemFwd2x4Bytes, s, *e, parity);
             else
 #elif defined(NDP_EXPERIMENT_FWD_LP)
