@@ -229,3 +229,28 @@ def test_h0_is_recomputed_by_the_split_backward_not_read_back(dev):
     for k in ("heads", "dO", "dz1", "g_bwd2", "g_all"):
         assert torch.equal(a[k], b[k]), k
     assert torch.equal(a["act_fwd"][1:], b["act_fwd"][1:])
+
+
+def test_loss_stage_leaves_the_pairs_largest_dO_for_the_gradient_scale(dev):
+    """e.gmax[b] after the loss stage = the bit pattern of max |dO| over the pair's points (wave maxima folded per workgroup, one
+    atomicMax of the non-negative float's bits per workgroup); the forward stage of the next tick starts it from zero again."""
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    pyr = seeded_pyramid(11, m=1, **VARIANTS["se3aa"])
+    scale_heads(pyr, 0, 20.0)
+    eng = BatchedEngine(pyr.descs[0], OptConfig(m=1, iters=4, early_stop=False), 2, n_cap=1024, t_cap=1024, device=dev, gemm_mode=7, nn_mode=1)
+    g = torch.Generator().manual_seed(5)
+    for b, S in enumerate((1000, 700)):
+        src = (torch.rand(S, 3, generator=g) - 0.5).contiguous()
+        tgt = ((torch.rand(900, 3, generator=g) - 0.5) * 1.05).contiguous()
+        eng.load(b, src, 0, S, None, tgt, pyr.store)
+    for tick in range(2):
+        eng.run_stages(0, 0)
+        torch.cuda.synchronize()
+        assert eng.gmax.cpu().tolist() == [0, 0]
+        eng.run_stages(1, 2)
+        torch.cuda.synchronize()
+        got = eng.gmax.cpu().view(torch.float32)
+        want = eng.dO.abs().amax(dim=(1, 2)).cpu()
+        assert torch.equal(got, want), (got, want)
+        assert float(want.min()) > 0
+        eng.run_stages(3, 5)
