@@ -134,8 +134,18 @@ def roofline_report(model, pairs, B, config):
     per_kernel = {"+".join(names[k]): {"ms": prof[k], "achieved_tflops": flops[k] * active / (prof[k] * 1e-3) / 1e12,
                                         "frac_of_its_peak": flops[k] * active / (prof[k] * 1e-3) / 1e12 / peak_of[k]}
                   for k in ("k_eng_fwd", "k_eng_nn", "k_eng_bwd2", "k_eng_bwd1")}
+    # the tick's own roofline: every stage at the peak of the pipe it runs on (contractions: FLOP / MFMA or vector peak; the update:
+    # its algorithmic bytes -- G gradient partials + parameters, two moments read and written -- at 8 TB/s), summed, against the
+    # measured tick.  The per-kernel table decides nothing here: a tie between two kernels cannot flip this fraction.
+    ideal = {k: flops[k] * active / (peak_of[k] * 1e12) * 1e3 for k in ("k_eng_fwd", "k_eng_nn", "k_eng_bwd2", "k_eng_bwd1")}
+    ideal["k_eng_update"] = (eng.G + 7) * 4 * P * active / 8e12 * 1e3
+    ideal_ms = sum(ideal.values())
     return {"roofline": roof, "kernels_ms_per_tick": {"+".join(names[k]): v for k, v in prof.items()}, "kernel_rooflines": per_kernel,
-            "tick": {"ms": tick_ms, "achieved_tflops": (algorithmic_flops(n, 0, P) + FLOP_NN_PAIR * S * T) * active / (tick_ms * 1e-3) / 1e12},
+            "tick": {"ms": tick_ms, "achieved_tflops": (algorithmic_flops(n, 0, P) + FLOP_NN_PAIR * S * T) * active / (tick_ms * 1e-3) / 1e12,
+                     "ideal_ms": ideal_ms, "frac": ideal_ms / tick_ms,
+                     "ideal_ms_by_stage": {"+".join(names[k]): v for k, v in ideal.items()},
+                     "ideal_is": "sum over stages of algorithmic FLOP / peak of the stage's pipe (split level kernels: 2500 / 3 TFLOP/s; "
+                                 "nearest neighbours: 157.3), update: algorithmic bytes / 8 TB/s; loss / decision stage: 0"},
             "engine_modes": {"gemm_mode": eng.gemm_mode, "nn_mode": eng.nn_mode, "G": eng.G}}
 
 
@@ -143,6 +153,8 @@ ARITH_TEXT = {0: "fp32 MFMA, bitwise the oracle's fma chain",
               7: "128x128 contractions of the three level kernels as two-way fp16 splits (x = hi + 2^-11 lo, three partial products, gradient "
                  "operands scaled by a power of two per pair) on the fp16 MFMA, fp32 accumulate: closer to float64 than the fp32 chain "
                  "(tests/test_split_accuracy.py), not bitwise the chain"}
+# `dtype` of the line: fp32 storage, fp32 accumulation and fp32-level accuracy in both arithmetics; the split one says how its products are formed
+DTYPE_TEXT = {0: "f32", 7: "f32 (fp16x2-split contractions, fp32 accumulate)"}
 NN_TEXT = {0: "one pass, distances on the vector pipe", 1: "latency shape (two passes, 64-query workgroups)",
            2: "one pass, distances on the bf16 matrix pipe + exact re-evaluation (bit-identical results)"}
 
@@ -444,7 +456,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32",
+        "dtype": DTYPE_TEXT.get(main_modes[0], "f32"),
         "data": "synthetic",
         "config": {"workload": workload, "survey_8d_config": args.config,
                    "contraction_arithmetic": ARITH_TEXT.get(main_modes[0], f"mask {main_modes[0]} (1 fwd | 2 bwd1 | 4 bwd2) on fp16 splits, the rest on the fp32 MFMA"),
@@ -476,7 +488,7 @@ def main():
         alt = {"name": "split (fp16x2 level kernels + matrix-pipe NN)" if main_modes[0] == 0 else "bitwise (fp32-MFMA level kernels + vector-pipe NN)",
                "value": args.alt_steps * NP / a_elapsed, "unit": "pairs/s", "steps": args.alt_steps, "warmup": 1,
                "ms_per_step": 1e3 * a_elapsed / args.alt_steps, "ms_per_iter": 1e3 * a_elapsed / max(a_steps, 1),
-               "adam_iters_per_pair": a_steps / (args.alt_steps * NP), "dtype": "f32",
+               "adam_iters_per_pair": a_steps / (args.alt_steps * NP), "dtype": DTYPE_TEXT.get(a_eng.gemm_mode, "f32"),
                "contraction_arithmetic": ARITH_TEXT[a_eng.gemm_mode], "nn_kernel": NN_TEXT[a_eng.nn_mode],
                "gemm_mode": a_eng.gemm_mode, "nn_mode": a_eng.nn_mode,
                "accuracy": {k: float(v / NP) for k, v in zip(a_keys, a_msum)}}
