@@ -95,12 +95,18 @@ def pmc_traffic(kernels, pairs):
 
 def stage_kernels(gemm_mode, nn_mode):
     """The launches behind each of the six tick stages (N.TICK_KERNELS order) for an engine's modes."""
+    fused = bwd_fused(gemm_mode)
     return {"k_eng_fwd": ["k_eng_fwd8", "k_eng_warp"] if gemm_mode & 1 else ["k_eng_fwd"],
             "k_eng_nn": [{0: "k_eng_nn", 1: "k_eng_nn_lat", 2: "k_eng_nn_mx"}[nn_mode]],
             "k_eng_loss": ["k_eng_loss"],
-            "k_eng_bwd2": ["k_eng_bwd2_8"] if gemm_mode & 4 else ["k_eng_bwd2"],
-            "k_eng_bwd1": ["k_eng_bwd1_8"] if gemm_mode & 2 else ["k_eng_bwd1"],
+            "k_eng_bwd2": ["k_eng_bwd_f"] if fused else (["k_eng_bwd2_8"] if gemm_mode & 4 else ["k_eng_bwd2"]),
+            "k_eng_bwd1": [] if fused else (["k_eng_bwd1_8"] if gemm_mode & 2 else ["k_eng_bwd1"]),
             "k_eng_update": ["k_eng_update"]}
+
+
+def bwd_fused(gemm_mode):
+    """Both backward layers of the split arithmetic in ONE launch (k_eng_bwd_f, round 4) -- stage 4 of the tick then launches nothing."""
+    return (gemm_mode & 6) == 6 and not gemm_mode & 16
 
 
 def roofline_report(model, pairs, B, config):
@@ -112,12 +118,17 @@ def roofline_report(model, pairs, B, config):
     S, T, n = preps[0].S, preps[0].T, preps[0].S + preps[0].K       # n: points through the MLP (landmarks + samples)
     P = eng.P
     names = stage_kernels(eng.gemm_mode, eng.nn_mode)
+    fused = bwd_fused(eng.gemm_mode)
+    if fused:                      # the empty stage's slot holds two event records back to back (~5 us), not a kernel: not part of the tick
+        prof = {k: v for k, v in prof.items() if k != "k_eng_bwd1"}
     dom = max(prof, key=prof.get)
     nh = preps[0].desc.n_heads                                       # head rows: 6 SE3, 7 Sim3 (+768 FLOP/pt)
     # backward split by layer: bwd2 = heads (dWh + dh2) + dW2 + dh1, bwd1 = dW1 + dh0 + dW0 (768 MAC)
     flops = {"k_eng_fwd": (FLOP_FWD_PT + 256 * (nh - 6)) * n, "k_eng_bwd2": 2 * (2 * 16384 + 256 * nh) * n,
              "k_eng_bwd1": 2 * (2 * 16384 + 768) * n, "k_eng_nn": FLOP_NN_PAIR * S * T,
              "k_eng_update": 12 * P, "k_eng_loss": 4 * (S + T)}
+    if fused:
+        flops["k_eng_bwd2"] += flops.pop("k_eng_bwd1")
     split = {"k_eng_fwd": eng.gemm_mode & 1, "k_eng_bwd1": eng.gemm_mode & 2, "k_eng_bwd2": eng.gemm_mode & 4}
     peak_of = {k: (BF16_PEAK_TFLOPS / SPLIT_PRODUCTS if split.get(k) else FP32_PEAK_TFLOPS) for k in prof}
     ach = flops[dom] * active / (prof[dom] * 1e-3) / 1e12
@@ -133,11 +144,11 @@ def roofline_report(model, pairs, B, config):
         roof["hbm_frac"] = roof["hbm_tbps"] / 8.0
     per_kernel = {"+".join(names[k]): {"ms": prof[k], "achieved_tflops": flops[k] * active / (prof[k] * 1e-3) / 1e12,
                                         "frac_of_its_peak": flops[k] * active / (prof[k] * 1e-3) / 1e12 / peak_of[k]}
-                  for k in ("k_eng_fwd", "k_eng_nn", "k_eng_bwd2", "k_eng_bwd1")}
+                  for k in ("k_eng_fwd", "k_eng_nn", "k_eng_bwd2", "k_eng_bwd1") if k in prof}
     # the tick's own roofline: every stage at the peak of the pipe it runs on (contractions: FLOP / MFMA or vector peak; the update:
     # its algorithmic bytes -- G gradient partials + parameters, two moments read and written -- at 8 TB/s), summed, against the
     # measured tick.  The per-kernel table decides nothing here: a tie between two kernels cannot flip this fraction.
-    ideal = {k: flops[k] * active / (peak_of[k] * 1e12) * 1e3 for k in ("k_eng_fwd", "k_eng_nn", "k_eng_bwd2", "k_eng_bwd1")}
+    ideal = {k: flops[k] * active / (peak_of[k] * 1e12) * 1e3 for k in ("k_eng_fwd", "k_eng_nn", "k_eng_bwd2", "k_eng_bwd1") if k in prof}
     ideal["k_eng_update"] = (eng.G + 7) * 4 * P * active / 8e12 * 1e3
     ideal_ms = sum(ideal.values())
     return {"roofline": roof, "kernels_ms_per_tick": {"+".join(names[k]): v for k, v in prof.items()}, "kernel_rooflines": per_kernel,

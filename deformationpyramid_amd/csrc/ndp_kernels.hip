@@ -1211,7 +1211,7 @@ k_eng_fwd(ndp_engine e, int parity) {
     PT_FLUSH(12);
 }
 
-#include "ndp_fwd_bf16.inc"
+#include "ndp_fwd_split.inc"
 #if defined(NDP_EXPERIMENT_FWD_2X4)
 #include "../../tools/experiments/ndp_fwd_2x4.inc"
 #endif
@@ -1845,7 +1845,8 @@ k_eng_bwd1(ndp_engine e, int parity) {
     PT_FLUSH(24);
 }
 
-#include "ndp_bwd_bf16.inc"
+#include "ndp_bwd_split.inc"
+#include "ndp_bwd_fused.inc"
 
 // fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state).
 // (Four parameters per thread on 16-byte accesses: no faster at 128 pairs -- 0.0305 against 0.0315 ms -- and TWICE as slow at batch 1,
@@ -2467,7 +2468,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (int rc = set_smem((const void *)k_eng_bwd2, kSmemBwdBytes)) return rc;
     if (int rc = set_smem((const void *)k_eng_bwd1, kSmemBwdBytes)) return rc;
     if (nn && e->nn_mode == 2) {
-        if (!nn2_fits(e->n_cap)) return fail(NDP_E_UNSUPPORTED, "ndp_engine_run: n_cap too large for nn_mode 2 (sources + column table must fit LDS)");
+        if (!nn2_fits(e->n_cap)) return fail(NDP_E_UNSUPPORTED, "ndp_engine_run: nn_mode 2 does not fit this n_cap (ndp_engine_nn_matrix_fits; the kernel walks the sources in passes of 2048, so this is not expected)");
         if (int rc = set_smem((const void *)k_eng_nn_mx, nn2_lds_floats(e->n_cap) * 4)) return rc;
     }
     const dim3 blk(256);
@@ -2475,7 +2476,10 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
     // partials per pair); in a mixed configuration they take half the fp32 grid and zero the partials they do not write.
     const dim3 g_fwd8(engine_g8(e), e->B);
-    if (e->gemm_mode < 0 || e->gemm_mode > 15) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0)");
+    if (e->gemm_mode < 0 || e->gemm_mode > 63) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1)");
+    // both backward layers on the splits: ONE launch (k_eng_bwd_f, stage 3; stage 4 launches nothing) unless bit 16 asks for the two round-3 kernels
+    const bool bwd_fused = (e->gemm_mode & 6) == 6 && !(e->gemm_mode & 16);
+    if (bwd_fused) if (int rc = set_smem((const void *)k_eng_bwd_f, kSmemBwdFBytes)) return rc;
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     const bool fwd_as = engine_fwd_as(e);
     (void)fwd_as;
@@ -2539,10 +2543,11 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         if (NDP_ST(2)) hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         NDP_EV();
         if (!NDP_ST(3)) {}
+        else if (bwd_fused) hipLaunchKernelGGL(k_eng_bwd_f, g_fwd8, dim3(512), kSmemBwdFBytes, s, *e, parity);
         else if (e->gemm_mode & 4) hipLaunchKernelGGL(k_eng_bwd2_8, g_fwd8, dim3(512), kSmemBwd8Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV();
-        if (!NDP_ST(4)) {}
+        if (!NDP_ST(4) || bwd_fused) {}
         else if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd18Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV();
@@ -2583,7 +2588,7 @@ extern "C" int ndp_chamfer_nn_matrix(const float *x, int S, const float *y, int 
     if (S <= 0 || T <= 0 || !x || !y || !d2x || !idx_x || !d2y || !idx_y || !ws_row)
         return fail(NDP_E_INVALID, "ndp_chamfer_nn_matrix: bad arguments");
     const int n_cap = (S + NDP_TILE - 1) / NDP_TILE * NDP_TILE;
-    if (!nn2_fits(n_cap)) return fail(NDP_E_UNSUPPORTED, "ndp_chamfer_nn_matrix: S too large (sources + column table must fit LDS)");
+    if (!nn2_fits(n_cap)) return fail(NDP_E_UNSUPPORTED, "ndp_chamfer_nn_matrix: does not fit this S (ndp_engine_nn_matrix_fits; the kernel walks the sources in passes of 2048, so this is not expected)");
     const int lds = nn2_lds_floats(n_cap) * 4;
     if (int rc = set_smem((const void *)k_nn2, lds)) return rc;
     hipStream_t s = (hipStream_t)stream;

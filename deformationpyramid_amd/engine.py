@@ -10,7 +10,6 @@ Memory per slot (n_cap = t_cap = 2048, m = 9): params 1.25 MB, activations 3 MB,
 gradient partials G x 0.14 MB -- hundreds of slots fit easily in 288 GB of HBM3E.
 """
 import ctypes
-import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -35,11 +34,14 @@ class OptConfig:
     early_stop: bool = True
 
 
-# Arithmetic of the three level kernels / shape of the nearest-neighbour kernel when the caller does not say (ctor argument >
-# environment NDP_GEMM_MODE / NDP_NN_MODE > these defaults):
-#   gemm_mode 7 (default since round 3): (mask 1 forward | 2 bwd1 | 4 bwd2) the 128x128 contractions as two-way fp16 splits (hi + 2^-11 lo,
-#                three products) on the fp16 MFMA with fp32 accumulation -- closer to a float64 evaluation than the fp32 chain is
-#                (tests/test_split_accuracy.py), every engine parity test passes at the same tolerances, but not bitwise the chain;
+# Arithmetic of the three level kernels / shape of the nearest-neighbour kernel when the caller does not say (constructor argument >
+# these defaults; nothing here reads the environment -- the measurement tools pass what they want, tools/_modes.py):
+#   gemm_mode 7 (default since round 3): (mask 1 forward | 2 bwd1 | 4 bwd2) the 128x128 contractions as two-way fp16 splits (three
+#                products) on the fp16 MFMA with fp32 accumulation -- closer to a float64 evaluation than the fp32 chain is
+#                (tests/test_split_accuracy.py), every engine parity test passes at the same tolerances, but not bitwise the chain.
+#                With both backward bits set the two backward layers run as ONE launch (k_eng_bwd_f, round 4: dz1 stays in LDS);
+#                + 16: as the two round-3 launches (k_eng_bwd2_8, k_eng_bwd1_8); + 32 (tests): the fused backward also writes dz1;
+#                + 8 (tests): the split forward also stores h0, which the split backward recomputes;
 #             0: the same contractions on the fp32 MFMA, bitwise the oracle's fma chain (Registration(cfg, gemm_mode=0),
 #                bench.py --gemm-mode 0) -- 1/16 of the 16-bit matrix rate;
 #   nn matrix : the one-pass NN with the distances on the bf16 matrix pipe and exact re-evaluation (bit-identical results).
@@ -53,11 +55,11 @@ def resolve_modes(B, n_cap, t_cap, gemm_mode=None, nn_mode=None, nn_matrix=None)
     nn_matrix (None: DEFAULT_NN_MATRIX) only states a preference for the throughput shape: matrix-pipe kernel where it fits."""
     lib = N.lib()
     if gemm_mode is None:
-        gemm_mode = int(os.environ.get("NDP_GEMM_MODE", DEFAULT_GEMM_MODE))
+        gemm_mode = DEFAULT_GEMM_MODE
     gemm_mode = int(gemm_mode)
-    if not 0 <= gemm_mode <= 15:
-        raise N.NdpError(f"gemm_mode must be a mask of 1 (forward) | 2 (bwd1) | 4 (bwd2) [| 8: the split forward also stores h0, "
-                         f"which bwd1 on the splits recomputes -- tests], got {gemm_mode}")
+    if not 0 <= gemm_mode <= 63:
+        raise N.NdpError(f"gemm_mode must be a mask of 1 (forward) | 2 (bwd1) | 4 (bwd2) [| 8: the split forward also stores h0 | 16: "
+                         f"the split backward as two launches | 32: the fused backward also writes dz1 -- tests], got {gemm_mode}")
     fits2 = bool(lib.ndp_engine_nn_matrix_fits(n_cap))
     fits0 = bool(lib.ndp_engine_nn_onepass_fits(n_cap))
     if nn_mode is not None:
@@ -68,10 +70,7 @@ def resolve_modes(B, n_cap, t_cap, gemm_mode=None, nn_mode=None, nn_matrix=None)
             raise N.NdpError(f"nn_mode {nn_mode}: n_cap = {n_cap} sources do not fit the kernel's LDS table "
                              "(ndp_engine_nn_matrix_fits / ndp_engine_nn_onepass_fits); use nn_mode 1 or leave the choice to the engine")
         return gemm_mode, nn_mode
-    env = os.environ.get("NDP_NN_MODE")
-    if env:                                          # experiments (tools/tick_bench.py): force a shape where it fits
-        want = int(env)
-    elif B * (t_cap // 256 + 1) < 256:               # few resident pairs: the one-pass kernels have only t_cap/256 workgroups per
+    if B * (t_cap // 256 + 1) < 256:               # few resident pairs: the one-pass kernels have only t_cap/256 workgroups per
         want = 1                                     # pair, the latency shape has (n_cap + t_cap)/64
     else:
         want = 2 if (DEFAULT_NN_MATRIX if nn_matrix is None else nn_matrix) else 0

@@ -86,9 +86,10 @@ typedef struct ndp_warp_job {
 #define NDP_MAX_WARP_JOBS 32
 int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_stride,
                           const ndp_warp_job *jobs, int n_jobs, void *stream);
-/* The same warp with the engine's split arithmetic (ndp_engine.gemm_mode & 1): 128-wide contractions as three-way bf16 splits on
- * the bf16 MFMA, fp32 accumulate; 256 points per workgroup carried through all m levels in LDS.  fp32-level accuracy (within
- * 1e-5 of ndp_pyramid_fwd_batch on warped coordinates), not bitwise the fma chain.                                              */
+/* The same warp with the engine's split arithmetic (ndp_engine.gemm_mode & 1): 128-wide contractions and layer 0 as two-way fp16
+ * splits (x = hi + 2^-11 lo, three partial products) on the fp16 MFMA, fp32 accumulate; 256 points per workgroup carried through
+ * all m levels in LDS.  fp32-level accuracy (within 1e-5 of ndp_pyramid_fwd_batch on warped coordinates), not bitwise the fma
+ * chain; operands beyond +-65504 saturate.                                                                                       */
 int ndp_pyramid_fwd_batch_split(const ndp_layer_desc *desc, int m, int k0, int p_stride,
                                 const ndp_warp_job *jobs, int n_jobs, void *stream);
 
@@ -251,9 +252,14 @@ typedef struct ndp_engine {
     int nn_mode, gemm_mode;          /* gemm_mode 0: level kernels on the fp32 MFMA, bitwise the oracle's fma chain.  Mask 1 forward,
                                         2 bwd1, 4 bwd2: their 128 x 128 contractions from two-way fp16 splits (hi + 2^-11 lo, three
                                         products, fp32 accumulate) on the 16-bit MFMA -- fp32-level accuracy, not bitwise the chain
-                                        (csrc/ndp_*_bf16.inc); 7 is what Registration uses by default.  With 1 | 2 the forward does
-                                        not store h0 (act[b][0] is left untouched): bwd1 recomputes it from the saved encoding with
-                                        the forward's own two MFMAs; bit 8 makes the forward store it all the same (tests).
+                                        (csrc/ndp_*_split.inc); 7 is what Registration uses by default.  With 1 | 2 the forward does
+                                        not store h0 (act[b][0] is left untouched): the backward recomputes it from the saved
+                                        encoding with the forward's own two MFMAs; bit 8 makes the forward store it all the same
+                                        (tests).  With 2 | 4 both backward layers run as ONE launch (k_eng_bwd_f,
+                                        csrc/ndp_bwd_fused.inc: dz1 stays in LDS, one accumulator per product on operands pre-scaled
+                                        by powers of two -- activations and weights beyond 1023 saturate there); bit 16: as the two
+                                        launches k_eng_bwd2_8 + k_eng_bwd1_8 instead; bit 32 (tests): the fused launch also writes
+                                        dz1 over the h2 plane of `act`, where the two-launch form leaves it.
                                         nn_mode 0: one-pass kernel, distances on the vector pipe; 2: the same on the bf16 matrix pipe
                                         with exact re-evaluation (bit-identical, needs ndp_engine_nn_matrix_fits(n_cap)); 1: latency
                                         shape -- two passes in 64-query workgroups, S/64 + T/64 of them per pair -- for a handful of

@@ -81,12 +81,13 @@ def test_bench_line_carries_both_arithmetic_configurations():
         split = r.get("gemm_mode", r.get("config", {}).get("gemm_mode")) == 7
         roof = r["roofline"]
         assert roof["unit"] == "TFLOP/s" and 0.05 < roof["frac"] < 1.0 and roof["achieved"] > 0
-        if roof["kernel"].startswith(("k_eng_fwd8", "k_eng_bwd1_8", "k_eng_bwd2_8")):
+        if roof["kernel"].startswith(("k_eng_fwd8", "k_eng_bwd_f")):
             assert split and abs(roof["peak"] - 2500.0 / 3) < 1e-6       # three fp16 products per fp32-equivalent product
         else:
             assert roof["peak"] == 157.3
-        assert r["value"] > 0 and r["dtype"] == "f32"
-        assert set(r["kernels_ms_per_tick"]) >= ({"k_eng_fwd8+k_eng_warp", "k_eng_bwd2_8", "k_eng_bwd1_8"} if split else {"k_eng_fwd", "k_eng_bwd2", "k_eng_bwd1"})
+        assert r["value"] > 0 and r["dtype"] == ("f32 (fp16x2-split contractions, fp32 accumulate)" if split else "f32")
+        assert set(r["kernels_ms_per_tick"]) >= ({"k_eng_fwd8+k_eng_warp", "k_eng_bwd_f"} if split else {"k_eng_fwd", "k_eng_bwd2", "k_eng_bwd1"})
+        assert 0.02 < r["tick"]["frac"] < 1.0 and abs(r["tick"]["frac"] * r["tick"]["ms"] - r["tick"]["ideal_ms"]) < 1e-9
     # same workload, same early-stop behaviour: iterations per pair agree to a percent, accuracy to a few percent
     assert abs(rec["adam_iters_per_pair"] - alt["adam_iters_per_pair"]) < 0.02 * rec["adam_iters_per_pair"]
     assert abs(rec["accuracy"]["full-epe"] - alt["accuracy"]["full-epe"]) < 0.05 * rec["accuracy"]["full-epe"]

@@ -352,7 +352,7 @@ def test_stale_library_is_detected_by_its_build_id(tmp_path):
 
 
 def test_two_way_fp16_split_model_is_as_exact_as_fp32():
-    """The arithmetic of the split level kernels (csrc/ndp_fwd_bf16.inc), modelled in numpy: x = hi + 2^-11 lo with hi = fp16(x),
+    """The arithmetic of the split level kernels (csrc/ndp_fwd_split.inc), modelled in numpy: x = hi + 2^-11 lo with hi = fp16(x),
     lo = fp16(2^11 (x - hi)) represents x to within 2^-23 |x| -- one fp32 ulp -- and a 128-term contraction from the
     three products hi.hi + 2^-11 (hi.lo + lo.hi), accumulated in fp32, is at least as close to float64 as the fp32 chain.  An
     UNSCALED lo (fp16(x - hi)) is not: the remainder of a weight of 0.09 is a subnormal."""

@@ -27,7 +27,7 @@ def dev():
     return torch.device("cuda:0")
 
 
-def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_cd=1.0, tiny_h0=False, b1=None, keep_h0=True):
+def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_cd=1.0, tiny_h0=False, b1=None, keep_h0=True):  # noqa: C901
     """One tick of a one-pair engine at `level`, stage by stage; returns every buffer a kernel consumed or produced (CPU, fp32).
     w_cd: weight of the loss (every gradient scales with it).  tiny_h0: layer 0 of the level = (W0 = 0, b0 = 1e-9), i.e. every
     h0 is positive and below fp16's smallest subnormal (and h1 = relu(1e-9 W1 1 + b1) has such elements too)."""
@@ -48,7 +48,9 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
     cfg = OptConfig(m=m, iters=2, early_stop=False, w_cd=w_cd)
     # gemm_mode 7: the split forward does not store h0 (bwd1 recomputes it); bit 8 makes it store h0 for the comparisons below --
     # test_h0_is_recomputed... pins that the bit changes nothing else
-    eng = BatchedEngine(d, cfg, 1, n_cap=S, t_cap=T, device=dev, gemm_mode=(15 if gemm_mode == 7 and keep_h0 else gemm_mode), nn_mode=1, G=G)
+    # + 32: the fused backward (one launch for both layers, dz1 in LDS) also writes dz1 to HBM, where the two-launch form leaves it
+    mode = gemm_mode if (gemm_mode & 6) != 6 else (gemm_mode | (0 if gemm_mode & 16 else 32) | (8 if keep_h0 else 0))
+    eng = BatchedEngine(d, cfg, 1, n_cap=S, t_cap=T, device=dev, gemm_mode=mode, nn_mode=1, G=G)
     g = torch.Generator().manual_seed(3)
     src = (torch.rand(S, 3, generator=g) - 0.5).contiguous()
     tgt = ((torch.rand(T, 3, generator=g) - 0.5) * 1.05 + 0.02).contiguous()
@@ -202,9 +204,11 @@ def test_relu_masks_of_the_split_backward_see_activations_below_fp16s_range(dev)
     assert float(ref["db0"].abs().max()) > 0 and float(ref["dz1"].abs().max()) > 0
     for k in ("dz1", "dW0", "db0", "db1"):
         assert e[k][0] < 5e-6, (k, e[k])
-    # dW1 = dz1^T h0 is built from the VALUES of those activations: a two-way fp16 split carries an absolute error of up to
-    # 2^-36 = 1.5e-11 per operand element (half a subnormal step of lo, times 2^-11) -- nothing beside O(1) activations, 1.5 % of 1e-9
-    assert e["dW1"][0] < 0.03, e["dW1"]
+    # dW1 = dz1^T h0 is built from the VALUES of those activations.  The fused backward splits 2^6 h (one accumulator per product,
+    # lo unscaled): its absolute floor per operand element is half an fp16 subnormal step over 2^6 = 2^-31 = 4.7e-10 -- nothing
+    # beside O(1) activations, but 2^6 x 1e-9 = 6.4e-8 is ONE subnormal step of hi and a lo that rounds to zero: 7 % off.  (The
+    # two-launch backward, lo scaled by 2^11: floor 2^-36, 1.5 % of 1e-9.)
+    assert e["dW1"][0] < 0.08, e["dW1"]
 
 
 def test_activations_beyond_fp16s_range_saturate(dev):
@@ -254,3 +258,19 @@ def test_loss_stage_leaves_the_pairs_largest_dO_for_the_gradient_scale(dev):
         assert torch.equal(got, want), (got, want)
         assert float(want.min()) > 0
         eng.run_stages(3, 5)
+
+
+@pytest.mark.parametrize("tag,level", [("se3aa", 0), ("sim3eu", 0)])       # level 0: the two engines have seen the same ticks
+def test_fused_backward_agrees_with_the_two_launch_backward(dev, tag, level):
+    """The one-launch backward (k_eng_bwd_f: both layers per tile, dz1 in LDS, one accumulator per product on pre-scaled splits)
+    against the two round-3 launches (k_eng_bwd2_8 + k_eng_bwd1_8, gemm_mode bit 16: main + correction accumulators) on the same
+    forward state: the two arithmetics differ in how the three partial products are summed, so the bar is the one both hold against
+    float64 -- every gradient tensor within 2e-6 of its own scale -- not bit equality.  Stage 4 of the fused tick launches nothing."""
+    a = _run_tick_by_stages(dev, tag, 7, 2000, 2000, level, 20.0, G=2)          # fused (+ dz1 dump)
+    b = _run_tick_by_stages(dev, tag, 7 | 16, 2000, 2000, level, 20.0, G=2)     # two launches
+    assert torch.equal(a["dO"], b["dO"]) and torch.equal(a["act_fwd"], b["act_fwd"])
+    assert torch.equal(a["g_bwd2"], a["g_all"])                                  # the fused stage 3 is the whole backward
+    ka, kb = _kernel_outputs(a), _kernel_outputs(b)
+    for k in ("dWh", "dbh", "dW2", "db2", "dz1", "dW1", "db1", "dW0", "db0"):
+        err = float((ka[k] - kb[k]).abs().max() / kb[k].abs().max().clamp_min(1e-300))
+        assert err < 2e-6, (k, err)

@@ -25,7 +25,9 @@ from deformationpyramid_amd.synthetic import synthetic_pair
 
 dev = torch.device("cuda:0")
 cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
-model = Registration(cfg)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _modes import from_env
+model = Registration(cfg, **from_env())
 preps = [model._prepare(*[t.to(dev) for t in synthetic_pair(i)[:2]], None) for i in range(B)]
 eng = model._engine(B, preps[0])
 eng.load_jobs([p.load_job(b) for b, p in enumerate(preps)][:16])
@@ -92,14 +94,24 @@ if eng.nn_mode == 2:
     print(f"nn_mx: {tot / wgs:.0f} cycles per workgroup (all sources x 256 targets; thread 0 wall)")
     for i, nm in enumerate(nmn):
         print(f"   {nm:58s} {buf[64 + i] / wgs:9.0f}  {100.0 * buf[64 + i] / max(tot, 1):5.1f} %")
-if eng.gemm_mode & 4:
+FUSED = (eng.gemm_mode & 6) == 6 and not (eng.gemm_mode & 16)
+if FUSED:
+    nmf = ["top barrier (incl. wait for the requested rows)", "stage 1: h1 split, h2 tile, dO / encoding rows -> LDS", "barrier",
+           "stage 2: dWh (fp32 MFMA), dz2 chain + split, h0 recompute + split", "barrier", "wgrad2 (24 MFMA 32x32x16)",
+           "dgrad2 (48 MFMA 16x16x32) + mask + dz1 split -> planes", "barrier", "wgrad1 (24 MFMA) + the next tile's requests",
+           "dgrad1 (48 MFMA, swapped) + mask + [dW0 | db0]"]
+    tot = sum(buf[24 + i] for i in range(12))
+    print(f"bwd_f (fused): {tot / tiles:.0f} cycles per tile (thread 0 wall)")
+    for i, nm in enumerate(nmf):
+        print(f"   {nm:66s} {buf[24 + i] / tiles:9.0f}  {100.0 * buf[24 + i] / max(tot, 1):5.1f} %")
+if eng.gemm_mode & 4 and not FUSED:
     nm2 = ["top barrier (incl. wait for the requested rows)", "h1 split + h2 tile + dO rows -> LDS", "barrier", "dz2 chain (VALU) + split -> planes", "barrier",
            "dWh (fp32 MFMA 16x16x4)", "wgrad (24 MFMA 32x32x16)", "dgrad (48 MFMA 16x16x32) + mask + dz1 store", "tail: dW store, bias sums (once)"]
     tot = sum(buf[i] for i in range(12))
     print(f"bwd2_8: {tot / tiles:.0f} cycles per tile (thread 0 wall)")
     for i, nm in enumerate(nm2):
         print(f"   {nm:52s} {buf[i] / tiles:9.0f}  {100.0 * buf[i] / max(tot, 1):5.1f} %")
-if eng.gemm_mode & 2:
+if eng.gemm_mode & 2 and not FUSED:
     n_arr = max(buf[24 + 8], 1)
     print("bwd1_8: mean lateness of wave w at the top-of-tile barrier relative to wave 0 (cycles):", [round(buf[24 + w] / n_arr) for w in range(8)])
 if False:

@@ -13,7 +13,9 @@ ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 torch.set_num_threads(8)
 dev = torch.device("cuda:0")
 cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
-model = Registration(cfg)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _modes import from_env
+model = Registration(cfg, **from_env())
 preps = []
 for i in range(B):
     s, t, _, _ = synthetic_pair(i)

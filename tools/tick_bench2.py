@@ -15,7 +15,9 @@ G = int(sys.argv[4]) if len(sys.argv) > 4 else None
 torch.set_num_threads(8)
 dev = torch.device("cuda:0")
 cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
-model = Registration(cfg)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _modes import from_env
+model = Registration(cfg, **from_env())
 engs, streams = [], []
 for e in range(E):
     preps = []
