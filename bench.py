@@ -219,6 +219,83 @@ def _cpu_info():
     return model, physical, logical
 
 
+def _cpu_pair(cfg, src, tgt, k, threads, kinds=("port-c", "port-torch")):
+    """One full register() of the reference's per-pair path on the host, by each of the parity-pinned ports -> {kind: (seconds, Adam steps)}."""
+    from oracle import ndp_oracle as O
+    from oracle import ndp_torch_ref as T
+    from deformationpyramid_amd.nets import Deformation_Pyramid
+    torch.manual_seed(k)
+    pyr = Deformation_Pyramid(depth=cfg.depth, width=cfg.width, device="cpu", k0=cfg.k0, m=cfg.m,
+                              rotation_format=cfg.rotation_format, motion=cfg.motion_type)
+    d = pyr.descs[0]
+    cd = O.make_desc(d.width, d.n_hidden, d.motion, d.rotfmt, d.nonrigidity, d.mlp_scale)
+    src_c = src.cpu() - src.cpu().mean(0, keepdim=True)
+    tgt_c = tgt.cpu() - tgt.cpu().mean(0, keepdim=True)
+    s = src_c[torch.randperm(src_c.shape[0])[: cfg.samples]].contiguous()
+    t = tgt_c[torch.randperm(tgt_c.shape[0])[: cfg.samples]].contiguous()
+    out = {}
+    if "port-c" in kinds:
+        pa = np.concatenate([pyr.store[i, :d.param_count].numpy() for i in range(cfg.m)])
+        t0 = time.perf_counter()
+        r = O.optimize([cd] * cfg.m, pa, s.numpy(), 0, s.shape[0], None, t.numpy(), k0=cfg.k0, iters=cfg.iters,
+                       max_break_count=cfg.max_break_count, ratio=cfg.break_threshold_ratio, lr=cfg.lr, nthreads=threads)
+        O.pyramid_fwd([cd] * cfg.m, cfg.k0, r["params_all"], src_c.numpy(), nthreads=threads)
+        out["port-c"] = (time.perf_counter() - t0, int(r["steps"]))
+    if "port-torch" in kinds:
+        t0 = time.perf_counter()
+        levels, _, _, steps = T.optimize(pyr.store[:, :d.param_count], s, t, m=cfg.m, k0=cfg.k0, iters=cfg.iters, lr=cfg.lr,
+                                         max_break_count=cfg.max_break_count, ratio=cfg.break_threshold_ratio)
+        T.pyramid_forward(levels, src_c, cfg.k0)
+        out["port-torch"] = (time.perf_counter() - t0, int(steps))
+    return out
+
+
+def cpu_worker(idx, nproc, threads, kind, n_pairs):
+    """`bench.py --cpu-worker idx nproc threads kind pairs`: one of the nproc concurrent processes of the whole-box CPU baseline --
+    pinned to its own slice of `threads` cores, 1 warm-up pair, then n_pairs full pairs of its own (synthetic_pair(1000 + ...)); prints
+    one JSON line with its per-pair seconds.  The processes start together and run the same amount of work, so their timed pairs overlap."""
+    cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        os.sched_setaffinity(0, set(cpus[idx * threads:(idx + 1) * threads]) or set(cpus))
+    except (AttributeError, OSError):
+        pass
+    torch.set_num_threads(threads)
+    from oracle import ndp_oracle as O
+    O.lib()
+    ts, its = [], []
+    for q in range(n_pairs + 1):
+        src, tgt, _, _ = synthetic_pair(1000 + idx * 16 + q)
+        dt, steps = _cpu_pair(cfg, src, tgt, 1000 + idx * 16 + q, threads, kinds=(kind,))[kind]
+        if q:
+            ts.append(dt); its.append(steps)
+    print(json.dumps({"idx": idx, "s_per_pair": ts, "adam_iters": its}))
+
+
+def cpu_baseline_whole_box(kind, threads, physical, n_pairs=2):
+    """SURVEY 8(d)'s optional figure: the WHOLE host -- one process per `threads`-core slice (physical // threads of them), each on its
+    own pairs, all at once.  -> dict or None."""
+    import subprocess
+    nproc = max(1, physical // threads)
+    if nproc < 2:
+        return None
+    env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), str(nproc), str(threads), kind, str(n_pairs)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(nproc)]
+    recs = []
+    for pr in procs:
+        out, _ = pr.communicate(timeout=900)
+        for ln in out.splitlines():
+            if ln.startswith("{"):
+                recs.append(json.loads(ln))
+    if len(recs) != nproc:
+        return None
+    rate = sum(len(r["s_per_pair"]) / sum(r["s_per_pair"]) for r in recs)
+    return {"value": rate, "unit": "pairs/s", "cores": nproc * threads, "processes": nproc, "threads_per_process": threads, "kind": kind,
+            "sample": f"{nproc} concurrent processes x {threads} threads on disjoint core slices, each 1 warm-up + {n_pairs} full 8192-pt pairs of its own",
+            "s_per_pair": [[round(x, 3) for x in r["s_per_pair"]] for r in sorted(recs, key=lambda r: r["idx"])]}
+
+
 def cpu_baseline(cfg, pairs):
     """The reference's per-pair path on this box's host cores, two ways, both parity-pinned test infrastructure:
       port-c     oracle/ndp_oracle.c -- the bit-faithful scalar C restatement, OpenMP over the points;
@@ -227,10 +304,9 @@ def cpu_baseline(cfg, pairs):
     Fixed policy (no calibration): threads = min(physical cores, 32) -- OpenMP over 2000 points and 128-wide GEMMs stop
     scaling there -- the process restricted to that many cores, 1 warm-up pair, then 3 pairs (the bench's pairs 1..3,
     NDP.yaml unchanged, full register() work incl. the 8192-pt final warp); value = pairs / total seconds of the faster
-    port, spread = (max - min) / median of its per-pair times."""
+    port, spread = (max - min) / median of its per-pair times.  `whole_box`: the faster port again as one process per
+    32-core slice, all slices at once (what the whole host delivers on independent pairs)."""
     from oracle import ndp_oracle as O
-    from oracle import ndp_torch_ref as T
-    from deformationpyramid_amd.nets import Deformation_Pyramid
     model_name, physical, logical = _cpu_info()
     threads = max(1, min(physical, 32))
     aff = None
@@ -246,29 +322,10 @@ def cpu_baseline(cfg, pairs):
     iters = {"port-c": [], "port-torch": []}
     try:
         for k, (src, tgt) in enumerate(pairs[:4]):
-            torch.manual_seed(k)
-            pyr = Deformation_Pyramid(depth=cfg.depth, width=cfg.width, device="cpu", k0=cfg.k0, m=cfg.m,
-                                      rotation_format=cfg.rotation_format, motion=cfg.motion_type)
-            d = pyr.descs[0]
-            cd = O.make_desc(d.width, d.n_hidden, d.motion, d.rotfmt, d.nonrigidity, d.mlp_scale)
-            src_c = src.cpu() - src.cpu().mean(0, keepdim=True)
-            tgt_c = tgt.cpu() - tgt.cpu().mean(0, keepdim=True)
-            s = src_c[torch.randperm(src_c.shape[0])[: cfg.samples]].contiguous()
-            t = tgt_c[torch.randperm(tgt_c.shape[0])[: cfg.samples]].contiguous()
-            pa = np.concatenate([pyr.store[i, :d.param_count].numpy() for i in range(cfg.m)])
-            t0 = time.perf_counter()
-            r = O.optimize([cd] * cfg.m, pa, s.numpy(), 0, s.shape[0], None, t.numpy(), k0=cfg.k0, iters=cfg.iters,
-                           max_break_count=cfg.max_break_count, ratio=cfg.break_threshold_ratio, lr=cfg.lr, nthreads=threads)
-            O.pyramid_fwd([cd] * cfg.m, cfg.k0, r["params_all"], src_c.numpy(), nthreads=threads)
-            dt_c = time.perf_counter() - t0
-            t0 = time.perf_counter()
-            levels, _, _, steps = T.optimize(pyr.store[:, :d.param_count], s, t, m=cfg.m, k0=cfg.k0, iters=cfg.iters, lr=cfg.lr,
-                                             max_break_count=cfg.max_break_count, ratio=cfg.break_threshold_ratio)
-            T.pyramid_forward(levels, src_c, cfg.k0)
-            dt_t = time.perf_counter() - t0
+            res = _cpu_pair(cfg, src, tgt, k, threads)
             if k:                                          # pair 0 is the warm-up
-                runs["port-c"].append(dt_c); iters["port-c"].append(int(r["steps"]))
-                runs["port-torch"].append(dt_t); iters["port-torch"].append(int(steps))
+                for kind, (dt, steps) in res.items():
+                    runs[kind].append(dt); iters[kind].append(steps)
     finally:
         torch.set_num_threads(old_threads)
         if aff is not None:
@@ -280,10 +337,16 @@ def cpu_baseline(cfg, pairs):
                      "ms_per_iter": 1e3 * sum(ts) / max(sum(iters[kind]), 1), "adam_iters": iters[kind],
                      "spread": (max(ts) - min(ts)) / med}
     best = max(rep, key=lambda k: rep[k]["pairs_per_s"])
+    whole = None
+    try:
+        whole = cpu_baseline_whole_box(best, threads, physical)
+    except Exception as exc:                               # the whole-box leg is a second opinion: never fail the line for it
+        whole = {"error": repr(exc)}
     return {"value": rep[best]["pairs_per_s"], "unit": "pairs/s", "cores": threads, "kind": best,
             "sample": f"1 warm-up + {len(runs[best])} full 8192-pt pairs, NDP.yaml unchanged, register() work incl. the final warp; "
                       f"{threads} threads on {threads} of {physical} physical cores ({logical} logical), {model_name}",
-            "ms_per_iter": rep[best]["ms_per_iter"], "cpu_model": model_name, "physical_cores": physical, "ports": rep}
+            "ms_per_iter": rep[best]["ms_per_iter"], "cpu_model": model_name, "physical_cores": physical, "ports": rep,
+            "whole_box": whole}
 
 
 def self_launch(n):
@@ -303,6 +366,9 @@ def self_launch(n):
 
 
 def main():
+    if len(sys.argv) >= 7 and sys.argv[1] == "--cpu-worker":
+        cpu_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5], int(sys.argv[6]))
+        return
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)

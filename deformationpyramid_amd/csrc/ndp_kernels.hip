@@ -1212,18 +1212,6 @@ k_eng_fwd(ndp_engine e, int parity) {
 }
 
 #include "ndp_fwd_split.inc"
-#if defined(NDP_EXPERIMENT_FWD_2X4)
-#include "../../tools/experiments/ndp_fwd_2x4.inc"
-#endif
-#if defined(NDP_EXPERIMENT_FWD_AS2)
-#include "../../tools/experiments/ndp_fwd_as2.inc"
-#endif
-#if defined(NDP_EXPERIMENT_FWD_AS) || defined(NDP_EXPERIMENT_FWD_AS16) || defined(NDP_EXPERIMENT_FWD_4W) || defined(NDP_EXPERIMENT_FWD_LP)   /* tools/experiments: other shapes of the bf16 forward */
-#include "../../tools/experiments/ndp_fwd_as.inc"
-#include "../../tools/experiments/ndp_fwd_as16.inc"
-#include "../../tools/experiments/ndp_fwd_4w.inc"
-#include "../../tools/experiments/ndp_fwd_lp.inc"
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // One-pass exact 1-NN for the engine: every squared distance d2(x_i, y_j) is evaluated ONCE and serves both
@@ -2435,16 +2423,8 @@ extern "C" int ndp_adam_step(float *params, const float *grads, float *m, float 
     return 0;
 }
 
-// workgroups per pair of the bf16 level kernels, and whether the forward among them is the activation-stationary one
+// workgroups per pair of the split level kernels
 static int engine_g8(const ndp_engine *e) { return (e->gemm_mode & 7) == 7 ? e->G : (e->G > 1 ? e->G / 2 : 1); }
-static bool engine_fwd_as(const ndp_engine *e) {
-#if defined(NDP_EXPERIMENT_FWD_AS) || defined(NDP_EXPERIMENT_FWD_AS16)
-    return (e->gemm_mode & 1) && (e->n_cap / NDP_TILE) >= 4 * engine_g8(e);
-#else
-    (void)e;
-    return false;
-#endif
-}
 
 // one tick = NDP_TICK_KERNELS launches; ev (optional): NDP_TICK_KERNELS + 1 events per tick recorded around them
 // stages [stage_lo, stage_hi] of every tick: 0 forward, 1 nearest neighbours, 2 loss / decision / dL/dx', 3 bwd2, 4 bwd1, 5 update
@@ -2481,21 +2461,6 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     const bool bwd_fused = (e->gemm_mode & 6) == 6 && !(e->gemm_mode & 16);
     if (bwd_fused) if (int rc = set_smem((const void *)k_eng_bwd_f, kSmemBwdFBytes)) return rc;
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
-    const bool fwd_as = engine_fwd_as(e);
-    (void)fwd_as;
-#if defined(NDP_EXPERIMENT_FWD_AS2)
-    if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd_as2, kSmemFwdAs2Bytes)) return rc;
-#elif defined(NDP_EXPERIMENT_FWD_2X4)
-    if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd2x4, kSmemFwd2x4Bytes)) return rc;
-#elif defined(NDP_EXPERIMENT_FWD_LP)
-    if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd_lp, kSmemFwdLpBytes)) return rc;
-#elif defined(NDP_EXPERIMENT_FWD_4W)
-    if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd4w, kSmemFwd4wBytes)) return rc;
-#elif defined(NDP_EXPERIMENT_FWD_AS16)
-    if (fwd_as) if (int rc = set_smem((const void *)k_eng_fwd_as16, kSmemFwdAs16Bytes)) return rc;
-#elif defined(NDP_EXPERIMENT_FWD_AS)
-    if (fwd_as) if (int rc = set_smem((const void *)k_eng_fwd_as, kSmemFwdAsBytes)) return rc;
-#endif
     if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd18Bytes)) return rc;
     if (e->gemm_mode & 4) if (int rc = set_smem((const void *)k_eng_bwd2_8, kSmemBwd8Bytes)) return rc;
     const dim3 g_nn(nn1_row_chunks(e->t_cap), e->B);
@@ -2511,25 +2476,6 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         NDP_EV();
         if (!NDP_ST(0)) {}
         else if (e->gemm_mode & 1) {
-#if defined(NDP_EXPERIMENT_FWD_AS2)
-            if (true) hipLaunchKernelGGL(k_eng_fwd_as2, g_fwd8, dim3(512), kSmemFwdAs2Bytes, s, *e, parity);
-            else
-#elif defined(NDP_EXPERIMENT_FWD_2X4)
-            if (true) hipLaunchKernelGGL(k_eng_fwd2x4, dim3(2 * g_fwd8.x, e->B), dim3(256), kSmemFwd2x4Bytes, s, *e, parity);
-            else
-#elif defined(NDP_EXPERIMENT_FWD_LP)
-            if (true) hipLaunchKernelGGL(k_eng_fwd_lp, g_fwd8, dim3(512), kSmemFwdLpBytes, s, *e, parity);
-            else
-#elif defined(NDP_EXPERIMENT_FWD_4W)
-            if (true) hipLaunchKernelGGL(k_eng_fwd4w, g_fwd8, dim3(256), kSmemFwd4wBytes, s, *e, parity);
-            else
-#elif defined(NDP_EXPERIMENT_FWD_AS16)
-            if (fwd_as) hipLaunchKernelGGL(k_eng_fwd_as16, g_fwd8, dim3(1024), kSmemFwdAs16Bytes, s, *e, parity);
-            else
-#elif defined(NDP_EXPERIMENT_FWD_AS)
-            if (fwd_as) hipLaunchKernelGGL(k_eng_fwd_as, g_fwd8, dim3(512), kSmemFwdAsBytes, s, *e, parity);
-            else
-#endif
             hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity);
             hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
         }

@@ -64,7 +64,8 @@ names = {0: "bwd2 load+lds", 1: "bwd2 barrier", 2: "bwd2 mfma(outer+gemm)+db", 3
          5: "bwd2 barrier", 6: "bwd2 store", 7: "bwd2 barrier",
          24: "bwd1 load+lds", 25: "bwd1 barrier", 26: "bwd1 mfma(outer+gemm)", 27: "bwd1 barrier", 28: "bwd1 dz0 epilogue+db0",
          29: "bwd1 barrier", 30: "bwd1 dW0 (mfma16)", 31: "bwd1 barrier",
-         14: "fwd layer0", 15: "fwd barrier", 16: "fwd layer1+h0 store", 17: "fwd barrier", 18: "fwd layer2+h1 store",
+         12: "fwd weights -> registers (once per workgroup)", 15: "fwd encodings of a chunk of tiles", 18: "fwd a chunk's tiles (outer stamp)",
+         14: "fwd layer0", 16: "fwd layer1+h0 store", 17: "fwd barrier",
          19: "fwd barrier", 23: "fwd h2 store", 20: "fwd heads (mfma16)", 21: "fwd barrier"}
 print("per-tick ms [fwd nn loss bwd2 bwd1 upd]:", [round(x / ticks, 4) for x in ms])
 for grp, lo in (("bwd2", 0), ("fwd", 12), ("bwd1", 24)):
