@@ -272,7 +272,7 @@ def cpu_worker(idx, nproc, threads, kind, n_pairs):
     print(json.dumps({"idx": idx, "s_per_pair": ts, "adam_iters": its}))
 
 
-def cpu_baseline_whole_box(kind, threads, physical, n_pairs=2):
+def cpu_baseline_whole_box(kind, threads, physical, n_pairs=1):
     """SURVEY 8(d)'s optional figure: the WHOLE host -- one process per `threads`-core slice (physical // threads of them), each on its
     own pairs, all at once.  -> dict or None."""
     import subprocess
@@ -291,7 +291,13 @@ def cpu_baseline_whole_box(kind, threads, physical, n_pairs=2):
     if len(recs) != nproc:
         return None
     rate = sum(len(r["s_per_pair"]) / sum(r["s_per_pair"]) for r in recs)
-    return {"value": rate, "unit": "pairs/s", "cores": nproc * threads, "processes": nproc, "threads_per_process": threads, "kind": kind,
+    quota = None
+    try:                                                   # a container's CPU quota (cgroup v2): "max" or "<quota> <period>" microseconds
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    return {"value": rate, "cgroup_cpu_quota_cores": quota, "unit": "pairs/s", "cores": nproc * threads, "processes": nproc, "threads_per_process": threads, "kind": kind,
             "sample": f"{nproc} concurrent processes x {threads} threads on disjoint core slices, each 1 warm-up + {n_pairs} full 8192-pt pairs of its own",
             "s_per_pair": [[round(x, 3) for x in r["s_per_pair"]] for r in sorted(recs, key=lambda r: r["idx"])]}
 

@@ -25,6 +25,12 @@ python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_b1/*.db | head -1) $O/${T
 # whole bench under the kernel trace (short): share of the tick kernels, the final warps, the slot loads
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_bench -o bench -- python $R/bench.py --steps 2 --warmup 1 --no-alt --no-roofline --no-latency --no-cpu-baseline > $O/${TAG}_prof_bench.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_bench/*.db | head -1) $O/${TAG}_bench_kernel_stats.csv > /dev/null
+# the two-launch split backward of round 3 (gemm_mode 7 | 16) next to the fused one: kernel stats of the same tick
+NDP_GEMM_MODE=23 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_tick_2launch -o tick -- python $R/tools/tick_bench.py 128 24 > $O/${TAG}_prof_tick_2launch.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_tick_2launch/*.db | head -1) $O/${TAG}_tick_kernel_stats_2launch.csv > /dev/null
+# what the second and third engine buy
+bash $R/tools/experiments/sweep_engines.sh 2 > $O/${TAG}_engines_sweep.txt 2>&1
+cd /tmp
 # HBM traffic, both arithmetics merged into ONE file (kernel names differ: k_eng_fwd8 / k_eng_fwd ...)
 bash $R/tools/pmc_traffic.sh 128 8 > $O/${TAG}_hbm_split.json 2> $O/${TAG}_hbm_traffic_pmc.err
 NDP_GEMM_MODE=0 NDP_NN_MODE=0 bash $R/tools/pmc_traffic.sh 128 8 > $O/${TAG}_hbm_bitwise.json 2>> $O/${TAG}_hbm_traffic_pmc.err
@@ -34,6 +40,8 @@ a, b = json.load(open(sys.argv[1])), json.load(open(sys.argv[2]))
 b.update(a)                       # kernels common to both (nn variants aside: update, loss, load) keep the default arithmetic's numbers
 print(json.dumps(b, indent=1))
 PY
+NDP_GEMM_MODE=23 bash $R/tools/pmc_traffic.sh 128 8 > $O/${TAG}_hbm_traffic_2launch_pmc.json 2>> $O/${TAG}_hbm_traffic_pmc.err
 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_pmc.json
+NDP_GEMM_MODE=23 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_2launch_pmc.json
 NDP_GEMM_MODE=0 NDP_NN_MODE=0 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_bitwise_pmc.json
 ls -la $O | grep ${TAG}_
