@@ -2456,7 +2456,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
     // partials per pair); in a mixed configuration they take half the fp32 grid and zero the partials they do not write.
     const dim3 g_fwd8(engine_g8(e), e->B);
-    if (e->gemm_mode < 0 || e->gemm_mode > 63) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1)");
+    if (e->gemm_mode < 0 || e->gemm_mode > 127) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1), 64 (the Adam step inside the fused backward)");
     // both backward layers on the splits: ONE launch (k_eng_bwd_f, stage 3; stage 4 launches nothing) unless bit 16 asks for the two round-3 kernels
     const bool bwd_fused = (e->gemm_mode & 6) == 6 && !(e->gemm_mode & 16);
     if (bwd_fused) if (int rc = set_smem((const void *)k_eng_bwd_f, kSmemBwdFBytes)) return rc;
@@ -2497,7 +2497,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         else if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd18Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV();
-        if (NDP_ST(5)) hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        if (NDP_ST(5) && !(bwd_fused && (e->gemm_mode & 64))) hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
         NDP_EV();
 #undef NDP_ST
 #undef NDP_EV

@@ -57,9 +57,9 @@ def resolve_modes(B, n_cap, t_cap, gemm_mode=None, nn_mode=None, nn_matrix=None)
     if gemm_mode is None:
         gemm_mode = DEFAULT_GEMM_MODE
     gemm_mode = int(gemm_mode)
-    if not 0 <= gemm_mode <= 63:
+    if not 0 <= gemm_mode <= 127:
         raise N.NdpError(f"gemm_mode must be a mask of 1 (forward) | 2 (bwd1) | 4 (bwd2) [| 8: the split forward also stores h0 | 16: "
-                         f"the split backward as two launches | 32: the fused backward also writes dz1 -- tests], got {gemm_mode}")
+                         f"the split backward as two launches | 32: the fused backward also writes dz1 -- tests | 64: the Adam step inside the fused backward], got {gemm_mode}")
     fits2 = bool(lib.ndp_engine_nn_matrix_fits(n_cap))
     fits0 = bool(lib.ndp_engine_nn_onepass_fits(n_cap))
     if nn_mode is not None:
@@ -142,7 +142,7 @@ class BatchedEngine:
         self.state_nbytes = ctypes.sizeof(N.PairState)
         self.state = torch.zeros(2, B, self.state_nbytes, device=d, dtype=torch.uint8)
         self.geom = torch.zeros(B, 4, device=d, dtype=torch.int32)
-        self.gmax = torch.zeros(B, device=d, dtype=torch.int32)      # max |dO| per pair and tick: the split backward's gradient scale
+        self.gmax = torch.zeros(2 * B, device=d, dtype=torch.int32)  # [0, B): max |dO| per pair and tick, the split backward's gradient scale; [B, 2B): tickets of gemm_mode bit 64
         self._geom_h = np.zeros((B, 4), dtype=np.int32)
         self._state_h = torch.zeros(B, self.state_nbytes, dtype=torch.uint8).pin_memory()
         self._snap = [torch.zeros(B, self.state_nbytes, dtype=torch.uint8).pin_memory() for _ in range(2)]

@@ -250,10 +250,10 @@ def test_loss_stage_leaves_the_pairs_largest_dO_for_the_gradient_scale(dev):
     for tick in range(2):
         eng.run_stages(0, 0)
         torch.cuda.synchronize()
-        assert eng.gmax.cpu().tolist() == [0, 0]
+        assert eng.gmax[:2].cpu().tolist() == [0, 0]
         eng.run_stages(1, 2)
         torch.cuda.synchronize()
-        got = eng.gmax.cpu().view(torch.float32)
+        got = eng.gmax[:2].cpu().view(torch.float32)
         want = eng.dO.abs().amax(dim=(1, 2)).cpu()
         assert torch.equal(got, want), (got, want)
         assert float(want.min()) > 0
@@ -274,3 +274,31 @@ def test_fused_backward_agrees_with_the_two_launch_backward(dev, tag, level):
     for k in ("dWh", "dbh", "dW2", "db2", "dz1", "dW1", "db1", "dW0", "db0"):
         err = float((ka[k] - kb[k]).abs().max() / kb[k].abs().max().clamp_min(1e-300))
         assert err < 2e-6, (k, err)
+
+
+def test_adam_step_inside_the_fused_backward_is_bitwise_the_update_launch(dev):
+    """gemm_mode bit 64 (a measured variant): the last of a pair's backward workgroups to arrive folds the partials in index order
+    and applies Adam -- no k_eng_update launch.  Same fold order, same op sequence: parameters, moments and pair states are bitwise
+    those of the default tick after every tick of a short run that crosses level hand-overs (early stop on)."""
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    pyr = seeded_pyramid(5, m=3, **VARIANTS["se3aa"])
+    for lvl in range(3):
+        scale_heads(pyr, lvl, 20.0)
+    engs = []
+    for mode in (7, 7 | 64):
+        eng = BatchedEngine(pyr.descs[0], OptConfig(m=3, iters=6, early_stop=True), 3, n_cap=640, t_cap=640, device=dev, gemm_mode=mode, nn_mode=1, G=2)
+        g = torch.Generator().manual_seed(9)
+        for b, S in enumerate((600, 333, 64)):
+            src = (torch.rand(S, 3, generator=g) - 0.5).contiguous()
+            tgt = ((torch.rand(500, 3, generator=g) - 0.5) * 1.05).contiguous()
+            eng.load(b, src, 0, S, None, tgt, pyr.store)
+        engs.append(eng)
+    for tick in range(20):
+        for eng in engs:
+            eng.run_ticks(1)
+        torch.cuda.synchronize()
+        a, b = engs
+        assert torch.equal(a.params, b.params), tick
+        assert torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v), tick
+        assert [(s.level, s.iter, s.adam_t) for s in a.read_states()] == [(s.level, s.iter, s.adam_t) for s in b.read_states()]
+    assert max(s.level for s in engs[0].read_states()) >= 1                       # the run crossed a hand-over
