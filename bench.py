@@ -97,7 +97,7 @@ def stage_kernels(gemm_mode, nn_mode):
     """The launches behind each of the six tick stages (N.TICK_KERNELS order) for an engine's modes."""
     fused = bwd_fused(gemm_mode)
     return {"k_eng_fwd": ["k_eng_fwd8", "k_eng_warp"] if gemm_mode & 1 else ["k_eng_fwd"],
-            "k_eng_nn": [{0: "k_eng_nn", 1: "k_eng_nn_lat", 2: "k_eng_nn_mx"}[nn_mode]],
+            "k_eng_nn": [{0: "k_eng_nn", 1: "k_eng_nn_lat", 2: "k_eng_nn_mx" if gemm_mode & 128 else "k_eng_nn_mx8"}[nn_mode]],
             "k_eng_loss": ["k_eng_loss"],
             "k_eng_bwd2": ["k_eng_bwd_f"] if fused else (["k_eng_bwd2_8"] if gemm_mode & 4 else ["k_eng_bwd2"]),
             "k_eng_bwd1": [] if fused else (["k_eng_bwd1_8"] if gemm_mode & 2 else ["k_eng_bwd1"]),
@@ -167,7 +167,7 @@ ARITH_TEXT = {0: "fp32 MFMA, bitwise the oracle's fma chain",
 # `dtype` of the line: fp32 storage, fp32 accumulation and fp32-level accuracy in both arithmetics; the split one says how its products are formed
 DTYPE_TEXT = {0: "f32", 7: "f32 (fp16x2-split contractions, fp32 accumulate)"}
 NN_TEXT = {0: "one pass, distances on the vector pipe", 1: "latency shape (two passes, 64-query workgroups)",
-           2: "one pass, distances on the bf16 matrix pipe + exact re-evaluation (bit-identical results)"}
+           2: "one pass, distances on the bf16 matrix pipe + exact re-evaluation (bit-identical results), 512 targets per 8-wave workgroup"}
 
 
 def latency_profile(cfg, pairs, repeats=5, gemm_mode=None):

@@ -2450,13 +2450,16 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     if (nn && e->nn_mode == 2) {
         if (!nn2_fits(e->n_cap)) return fail(NDP_E_UNSUPPORTED, "ndp_engine_run: nn_mode 2 does not fit this n_cap (ndp_engine_nn_matrix_fits; the kernel walks the sources in passes of 2048, so this is not expected)");
         if (int rc = set_smem((const void *)k_eng_nn_mx, nn2_lds_floats(e->n_cap) * 4)) return rc;
+        if (nn2_lds_floats(e->n_cap, 8) * 4 <= 160 * 1024) if (int rc = set_smem((const void *)k_eng_nn_mx8, nn2_lds_floats(e->n_cap, 8) * 4)) return rc;
     }
+    // the matrix-pipe kernel in its 8-wave shape (512 targets per workgroup) unless gemm_mode bit 128 asks for the 4-wave one (A/B)
+    const bool nn_mx8 = nn && e->nn_mode == 2 && nn2_lds_floats(e->n_cap, 8) * 4 <= 160 * 1024 && !(e->gemm_mode & 128);
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
     // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
     // partials per pair); in a mixed configuration they take half the fp32 grid and zero the partials they do not write.
     const dim3 g_fwd8(engine_g8(e), e->B);
-    if (e->gemm_mode < 0 || e->gemm_mode > 127) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1), 64 (the Adam step inside the fused backward)");
+    if (e->gemm_mode < 0 || e->gemm_mode > 255) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1), 64 (the Adam step inside the fused backward)");
     // both backward layers on the splits: ONE launch (k_eng_bwd_f, stage 3; stage 4 launches nothing) unless bit 16 asks for the two round-3 kernels
     const bool bwd_fused = (e->gemm_mode & 6) == 6 && !(e->gemm_mode & 16);
     if (bwd_fused) if (int rc = set_smem((const void *)k_eng_bwd_f, kSmemBwdFBytes)) return rc;
@@ -2483,6 +2486,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         NDP_EV();
         if (!NDP_ST(1)) {}
         else if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);
+        else if (nn_mx8) hipLaunchKernelGGL(k_eng_nn_mx8, dim3((e->t_cap + 511) / 512, e->B), dim3(512), nn2_lds_floats(e->n_cap, 8) * 4, s, *e, parity);
         else if (nn && e->nn_mode == 2) hipLaunchKernelGGL(k_eng_nn_mx, g_nn, blk, nn2_lds_floats(e->n_cap) * 4, s, *e, parity);
         else if (nn) hipLaunchKernelGGL(k_eng_nn, g_nn, blk, nn_lds, s, *e, parity, stage_x);
         NDP_EV();

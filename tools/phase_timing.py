@@ -90,9 +90,10 @@ for lo, n, tag in ((36, wg_grad, "loss gradient workgroup"), (48, wg_dec, "loss 
 if eng.nn_mode == 2:
     nmn = ["setup: targets + B operands, sources -> LDS, |x|max", "A operands of a 128-source block (x4 per wave)", "distances: 8 tiles x (8 MFMA + row / column minima)",
            "rows: transposition, best class, exact evaluation", "barrier (waves done with their blocks)", "columns: fold table, exact re-scan of the winning block"]
-    wgs = B * ((eng.t_cap + 255) // 256) * ticks
+    mx8 = not (eng.gemm_mode & 128)                          # the 8-wave shape: 512 targets per workgroup
+    wgs = B * ((eng.t_cap + (511 if mx8 else 255)) // (512 if mx8 else 256)) * ticks
     tot = sum(buf[64 + i] for i in range(6))
-    print(f"nn_mx: {tot / wgs:.0f} cycles per workgroup (all sources x 256 targets; thread 0 wall)")
+    print(f"nn_mx{'8' if mx8 else ''}: {tot / wgs:.0f} cycles per workgroup (all sources x {512 if mx8 else 256} targets; thread 0 wall)")
     for i, nm in enumerate(nmn):
         print(f"   {nm:58s} {buf[64 + i] / wgs:9.0f}  {100.0 * buf[64 + i] / max(tot, 1):5.1f} %")
 FUSED = (eng.gemm_mode & 6) == 6 and not (eng.gemm_mode & 16)
