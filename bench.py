@@ -9,7 +9,7 @@
 `torch.distributed.run --nproc-per-node N` on 127.0.0.1, one rank per GPU, backend nccl (= RCCL); rank 0 prints the line.
 
 One *step* registers `--pairs-per-step` (default 32 x `--slots`) synthetic 8192-point pairs per GPU,
-`--slots` (default 128) per engine of them resident on the device at any time, with the shipped
+`--slots` (default 256) per engine of them resident on the device at any time, with the shipped
 NDP.yaml settings (SE3 / axis-angle, m = 9 levels, 2000 samples per cloud, lr 0.01, early stop on):
 per pair the full Registration.register() work -- pyramid init, centring, sampling, the level/Adam
 loop on the device, and the final warp of all 8192 source points.  The point clouds are resident in
@@ -379,11 +379,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--slots", type=int, default=128, help="pairs resident per GPU (= pairs per step per GPU)")
+    ap.add_argument("--slots", type=int, default=256, help="pairs resident per engine (256: one level-kernel workgroup per pair and CU -- the per-workgroup "
+                                                        "weight prologue over 32 tiles instead of 16; 128 until round 4)")
     ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 32 x slots)")
     ap.add_argument("--chunk", type=int, default=0, help="ticks between host polls (0: 4, or 8 for the landmark configuration E whose ticks are "
                                                           "four times shorter -- the per-chunk host work of three lanes must fit under one chunk of GPU work)")
-    ap.add_argument("--engines", type=int, default=3, help="independent engines (HIP streams) per GPU, `slots` pairs each")
+    ap.add_argument("--engines", type=int, default=2, help="independent engines (HIP streams) per GPU, `slots` pairs each (3 x 128 until round 4)")
     ap.add_argument("--config", default="A", choices=list("ABCDE"),
                     help="SURVEY 8(d) workload: A NDP.yaml faithful (the headline line); B fixed work (= --fixed-work); C samples = 8192; "
                          "D Sim3/euler, 6000 samples of 24 856-pt clouds (shape transfer); E LNDP.yaml, 500 landmarks, m = 10")

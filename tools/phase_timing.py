@@ -101,7 +101,7 @@ if FUSED:
     nmf = ["top barrier (incl. wait for the requested rows)", "stage 1: h1 split, h2 tile, dO / encoding rows -> LDS", "barrier",
            "stage 2: dWh (fp32 MFMA), dz2 chain + split, h0 recompute + split", "barrier", "wgrad2 (24 MFMA 32x32x16)",
            "dgrad2 (48 MFMA 16x16x32) + mask + dz1 split -> planes", "barrier", "wgrad1 (24 MFMA) + the next tile's requests",
-           "dgrad1 (48 MFMA, swapped) + mask + [dW0 | db0]"]
+           "dgrad1 (48 MFMA, swapped) + mask + [dW0 | db0]", "prologue: weight slices, staging (once per workgroup)", "tail: partial stores, bias sums (once per workgroup)"]
     tot = sum(buf[24 + i] for i in range(12))
     print(f"bwd_f (fused): {tot / tiles:.0f} cycles per tile (thread 0 wall)")
     for i, nm in enumerate(nmf):
