@@ -123,6 +123,9 @@ def build(force=False, verbose=False):
         fcntl.flock(lock, fcntl.LOCK_EX)
         if not force and not _stale():
             return LIBPATH
+        if source_id() is None:
+            raise NdpError(f"{LIBPATH} is missing (or carries no build id) and this deployment has no csrc/ to build it from: "
+                           "ship the prebuilt library with the package (its layout is checked against the Python structs by ndp_abi_sizes)")
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         if not os.path.exists(hipcc):
             raise NdpError("hipcc not found and libndp_hip.so is missing or stale")

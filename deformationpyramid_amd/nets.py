@@ -97,7 +97,25 @@ def _native_rng_ok():
             N.rng_replay([(700, -1.5, -0.25, 0), (333, 0.0, 1.0, -1), (1300, -0.0883883461356163, 0.0883883461356163, 700)],
                          out)
             r2 = torch.randperm(17)
-            _NATIVE_RNG["ok"] = bool(torch.equal(out[:700], a) and torch.equal(out[700:], b) and torch.equal(r1, r2))
+            ok = bool(torch.equal(out[:700], a) and torch.equal(out[700:], b) and torch.equal(r1, r2))
+            # the native randperm replay (ndp_pair_init's permutation prefixes, ndp_rng_skip's end state) against torch.randperm itself:
+            # a torch release that changes randperm_cpu sends every caller back to the torch-call path instead of silently changing the samples
+            import ctypes
+            torch.manual_seed(13579)
+            w1, w2 = torch.randperm(41), torch.randperm(7)
+            end = torch.get_rng_state().clone()
+            torch.manual_seed(13579)
+            st = torch.get_rng_state().clone()
+            L = N.host_lib()
+            ops0 = N.make_draw_ops([])
+            hi = torch.zeros(64, dtype=torch.int32)
+            scratch = torch.zeros(64, dtype=torch.int64)
+            dummy = torch.zeros(8)
+            rc = L.ndp_pair_init(ctypes.c_void_p(st.data_ptr()), st.numel(), ops0, 0, ctypes.c_void_p(dummy.data_ptr()), 41, 7, 20,
+                                 ctypes.c_void_p(hi.data_ptr()), ctypes.c_void_p(hi[20:].data_ptr()), ctypes.c_void_p(scratch.data_ptr()))
+            ok = ok and rc == 0 and torch.equal(hi[:20].long(), w1[:20]) and torch.equal(hi[20:27].long(), w2)
+            ok = ok and L.ndp_rng_skip(ctypes.c_void_p(st.data_ptr()), st.numel(), L.ndp_pair_draws(ops0, 0, 41, 7)) == 0 and torch.equal(st, end)
+            _NATIVE_RNG["ok"] = bool(ok)
             torch.set_rng_state(saved)
         except Exception:
             _NATIVE_RNG["ok"] = False

@@ -574,7 +574,8 @@ class Registration:
             if rc != 0:
                 raise N.NdpError("ndp_pair_init failed")
             if own:                                                                 # leave the global generator where torch would
-                L.ndp_rng_skip(ctypes.c_void_p(st.data_ptr()), st.numel(), L.ndp_pair_draws(ops_, len(ops_), n_src, n_tgt))
+                if L.ndp_rng_skip(ctypes.c_void_p(st.data_ptr()), st.numel(), L.ndp_pair_draws(ops_, len(ops_), n_src, n_tgt)) != 0:
+                    raise N.NdpError("ndp_rng_skip failed")
                 torch.set_rng_state(st)
         else:
             if rng_state is not None:

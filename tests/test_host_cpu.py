@@ -393,3 +393,42 @@ def test_two_way_fp16_split_model_is_as_exact_as_fp32():
 
     assert rms(three_products(2048.0)) <= rms(chain)
     assert rms(three_products(1.0)) > 1.5 * rms(chain)
+
+
+@pytest.mark.parametrize("n_src,n_tgt,keep,seed", [(8192, 8192, 2000, 0), (1, 5, 2000, 3), (2001, 777, 2000, 11), (24856, 24856, 6000, 5), (300, 300, 0, 7)])
+def test_native_pair_init_replays_torch_randperm_and_leaves_the_generator_where_torch_would(n_src, n_tgt, keep, seed):
+    """ndp_pair_init (init draws + the prefixes of BOTH sampling permutations from a generator-state snapshot) and ndp_rng_skip (the
+    generator state after a pair) against torch itself: the same uniform_ stream, the same torch.randperm(n)[:keep] prefixes, and a
+    generator that continues exactly where torch's would -- for full-size, tiny, ragged and shape-transfer sizes and keep = 0."""
+    import ctypes
+    from deformationpyramid_amd import _native as N
+    from deformationpyramid_amd.nets import _draw_ops, Deformation_Pyramid
+    L = N.host_lib()
+    torch.manual_seed(seed)
+    pyr = Deformation_Pyramid(depth=3, width=128, device="cpu", k0=-8, m=3, rotation_format="axis_angle", motion="SE3")   # torch path: init draws
+    want_s = torch.randperm(n_src)[:keep]
+    want_t = torch.randperm(n_tgt)[:keep]
+    after = torch.get_rng_state().clone()
+    follow = torch.rand(4)
+    # native replay from the same seed
+    torch.manual_seed(seed)
+    st = torch.get_rng_state().clone()
+    descs = pyr.descs
+    stride = pyr.store.shape[1]
+    ops_ = N.make_draw_ops(_draw_ops(descs, 3, stride))
+    n_par = 3 * stride
+    host = torch.zeros(n_par + 2 * max(keep, 1) + 8)
+    hi = host[n_par:].view(torch.int32)
+    scratch = torch.zeros(max(n_src, n_tgt) + 8, dtype=torch.int64)
+    rc = L.ndp_pair_init(ctypes.c_void_p(st.data_ptr()), st.numel(), ops_, len(ops_), ctypes.c_void_p(host.data_ptr()), n_src, n_tgt, keep,
+                         ctypes.c_void_p(hi.data_ptr()), ctypes.c_void_p(hi[keep:].data_ptr()), ctypes.c_void_p(scratch.data_ptr()))
+    assert rc == 0
+    store = host[:n_par].view(3, stride)
+    for i, d in enumerate(descs):
+        assert torch.equal(store[i, :d.param_count], pyr.store[i, :d.param_count]), i
+    ks, kt = min(keep, n_src), min(keep, n_tgt)
+    assert torch.equal(hi[:ks].long(), want_s[:ks]) and torch.equal(hi[keep:keep + kt].long(), want_t[:kt])
+    assert L.ndp_rng_skip(ctypes.c_void_p(st.data_ptr()), st.numel(), L.ndp_pair_draws(ops_, len(ops_), n_src, n_tgt)) == 0
+    assert torch.equal(st, after)
+    torch.set_rng_state(st)
+    assert torch.equal(torch.rand(4), follow)
