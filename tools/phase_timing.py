@@ -98,8 +98,8 @@ if eng.nn_mode == 2:
         print(f"   {nm:58s} {buf[64 + i] / wgs:9.0f}  {100.0 * buf[64 + i] / max(tot, 1):5.1f} %")
 FUSED = (eng.gemm_mode & 6) == 6 and not (eng.gemm_mode & 16)
 if FUSED:
-    nmf = ["top barrier (incl. wait for the requested rows)", "stage 1: h1 split, h2 tile, dO / encoding rows -> LDS", "barrier",
-           "stage 2: dWh (fp32 MFMA), dz2 chain + split, h0 recompute + split", "barrier", "wgrad2 (24 MFMA 32x32x16)",
+    nmf = ["top barrier (incl. wait for the requested rows)", "stage 1: h1 split, dbh, encoding rows -> LDS", "-",
+           "stage 2 (no barrier before it): dWh, dz2 chain + split", "barrier", "h0 recompute + split, wgrad2 (24 MFMA 32x32x16)",
            "dgrad2 (48 MFMA 16x16x32) + mask + dz1 split -> planes", "barrier", "wgrad1 (24 MFMA) + the next tile's requests",
            "dgrad1 (48 MFMA, swapped) + mask + [dW0 | db0]", "prologue: weight slices, staging (once per workgroup)", "tail: partial stores, bias sums (once per workgroup)"]
     tot = sum(buf[24 + i] for i in range(12))
