@@ -13,10 +13,12 @@ python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench_line.err
 for c in B C D E; do
   python bench.py --config $c --steps 2 --warmup 1 > $O/${TAG}_bench_config_$c.json 2> $O/${TAG}_bench_config_$c.err
 done
-python bench.py --slots 64 --engines 1 --steps 2 --warmup 1 --no-alt --no-latency --no-cpu-baseline > $O/${TAG}_bench_batch64.json 2> /dev/null
+python bench.py --slots 64 --engines 1 --pairs-per-step 2048 --steps 2 --warmup 1 --no-alt --no-latency --no-cpu-baseline > $O/${TAG}_bench_batch64.json 2> /dev/null
 cd /tmp && export TMPDIR=/tmp
 # rocprofv3 kernel stats of the tick: default (split) arithmetic, then the bitwise one
 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_tick -o tick -- python $R/tools/tick_bench.py 128 24 > $O/${TAG}_prof_tick.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_tick256 -o tick -- python $R/tools/tick_bench.py 256 24 > $O/${TAG}_prof_tick256.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_tick256/*.db | head -1) $O/${TAG}_tick_kernel_stats_256pairs.csv > /dev/null
 python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_tick/*.db | head -1) $O/${TAG}_tick_kernel_stats.csv > /dev/null
 NDP_GEMM_MODE=0 NDP_NN_MODE=0 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_tick_bitwise -o tick -- python $R/tools/tick_bench.py 128 24 > $O/${TAG}_prof_tick_bitwise.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_tick_bitwise/*.db | head -1) $O/${TAG}_tick_kernel_stats_bitwise.csv > /dev/null
