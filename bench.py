@@ -279,6 +279,16 @@ def cpu_baseline_whole_box(kind, threads, physical, n_pairs=1):
     nproc = max(1, physical // threads)
     if nproc < 2:
         return None
+    quota = None
+    try:                                                   # a container's CPU quota (cgroup v2): "max" or "<quota> <period>" microseconds
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except (OSError, ValueError, IndexError):
+        pass
+    if quota is not None and quota < 0.75 * nproc * threads:
+        # (measured on the GPU boxes of round 4: quota 16 cores -- four 32-thread processes then share what one of them already could not use)
+        return {"skipped": f"the container's CPU quota is {quota:g} cores: {nproc} x {threads} threads cannot run side by side",
+                "cgroup_cpu_quota_cores": quota, "processes": nproc, "threads_per_process": threads}
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(i), str(nproc), str(threads), kind, str(n_pairs)],
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True) for i in range(nproc)]
@@ -291,12 +301,6 @@ def cpu_baseline_whole_box(kind, threads, physical, n_pairs=1):
     if len(recs) != nproc:
         return None
     rate = sum(len(r["s_per_pair"]) / sum(r["s_per_pair"]) for r in recs)
-    quota = None
-    try:                                                   # a container's CPU quota (cgroup v2): "max" or "<quota> <period>" microseconds
-        q = open("/sys/fs/cgroup/cpu.max").read().split()
-        quota = None if q[0] == "max" else float(q[0]) / float(q[1])
-    except (OSError, ValueError, IndexError):
-        pass
     return {"value": rate, "cgroup_cpu_quota_cores": quota, "unit": "pairs/s", "cores": nproc * threads, "processes": nproc, "threads_per_process": threads, "kind": kind,
             "sample": f"{nproc} concurrent processes x {threads} threads on disjoint core slices, each 1 warm-up + {n_pairs} full 8192-pt pairs of its own",
             "s_per_pair": [[round(x, 3) for x in r["s_per_pair"]] for r in sorted(recs, key=lambda r: r["idx"])]}
