@@ -1013,12 +1013,14 @@ k_nn(const float *x, int S, const float *y, int T, float *d2x, int *idx_x, float
 // queries, one per lane; its four waves each scan a quarter of every 2048-reference stage (LDS, broadcast reads, the
 // same packed arithmetic and sub-chunk bookkeeping as nn_body), then the four candidates of a query are folded in
 // reference order (strict <: the earliest quarter keeps ties).  S/64 + T/64 workgroups per pair instead of S/512 + T/512.
+template <int NW = 4>
 __device__ __forceinline__ void nn_lat_body(const float *q, int nq, const float *r, int nr, float *d2, int *idx,
-                                            int qbase, float *sm /*[3][NN_STAGE] + [4][64] + [4][64]*/) {
+                                            int qbase, float *sm /*[3][NN_STAGE] + [NW][64] + [NW][64]*/) {
+    constexpr int NT = 64 * NW;                                     // threads of the workgroup: NW waves share the 64 queries
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     float *xs = sm, *ys = sm + NN_STAGE, *zs = sm + 2 * NN_STAGE;
     float *cb = sm + 3 * NN_STAGE;
-    int *ci = reinterpret_cast<int *>(cb + 256);
+    int *ci = reinterpret_cast<int *>(cb + NT);
     const int i = qbase + lane;
     float qc[3] = {0.f, 0.f, 0.f};
     if (i < nq) { qc[0] = q[3 * (size_t)i]; qc[1] = q[3 * (size_t)i + 1]; qc[2] = q[3 * (size_t)i + 2]; }
@@ -1030,22 +1032,22 @@ __device__ __forceinline__ void nn_lat_body(const float *q, int nq, const float 
         const int cpad = (cn + NN_SUB - 1) / NN_SUB * NN_SUB;
         __syncthreads();
         {
-            float v[NN_STAGE / 256][3];
+            float v[NN_STAGE / NT][3];
 #pragma unroll
-            for (int k = 0; k < NN_STAGE / 256; ++k) {
-                const int j = t + 256 * k;
+            for (int k = 0; k < NN_STAGE / NT; ++k) {
+                const int j = t + NT * k;
                 const float nanv = __builtin_nanf("");
                 v[k][0] = v[k][1] = v[k][2] = nanv;
                 if (j < cn) { const float *rp = r + 3 * (size_t)(c0 + j); v[k][0] = rp[0]; v[k][1] = rp[1]; v[k][2] = rp[2]; }
             }
 #pragma unroll
-            for (int k = 0; k < NN_STAGE / 256; ++k) {
-                const int j = t + 256 * k;
+            for (int k = 0; k < NN_STAGE / NT; ++k) {
+                const int j = t + NT * k;
                 if (j < cpad) { xs[j] = v[k][0]; ys[j] = v[k][1]; zs[j] = v[k][2]; }
             }
         }
         __syncthreads();
-        const int nsub = cpad / NN_SUB, per = (nsub + 3) / 4;                 // sub-chunks of this stage, per wave
+        const int nsub = cpad / NN_SUB, per = (nsub + NW - 1) / NW;           // sub-chunks of this stage, per wave
         for (int sc = wv * per; sc < min(nsub, (wv + 1) * per); ++sc) {
             float m = INFINITY;
 #pragma unroll
@@ -1080,7 +1082,7 @@ __device__ __forceinline__ void nn_lat_body(const float *q, int nq, const float 
         float b = cb[lane];
         int k = ci[lane];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NW; ++w) {
             const float v = cb[64 * w + lane];
             const int kv = ci[64 * w + lane];
             if (v < b || (v == b && kv >= 0 && (k < 0 || kv < k))) { b = v; k = kv; }
@@ -1525,19 +1527,53 @@ k_nn1_rows(int S, int T, int n_cap, const float *ws_row, float *d2x, int *idx_x)
 //                     term, then the targets whose nearest source point it is, in ascending target
 //                     index (the order a sequential CPU scatter-add produces), no atomics.
 #define LG_CHUNK 2048
-extern "C" __global__ void __launch_bounds__(256)
-k_eng_loss(ndp_engine e, int parity) {
-    __shared__ float red[256];
-    __shared__ int cnt[256], start[256];                                  // per-point bucket sizes / offsets
-    __shared__ int order[LG_CHUNK];                                       // targets grouped by their nearest source point
-    __shared__ __attribute__((aligned(16))) float rows[256 * NDP_NHMAX];  // per-thread head rows
-    const int b = blockIdx.y, t = threadIdx.x;
+struct LossSmem {
+    float red[256];
+    int cnt[256], start[256];                                             // per-point bucket sizes / offsets
+    int order[LG_CHUNK];                                                  // targets grouped by their nearest source point
+    __attribute__((aligned(16))) float rows[256 * NDP_NHMAX];             // per-thread head rows
+};
+// block reductions over the 256 ACTIVE threads of a workgroup (t: their index; the others only keep the barriers company -- the
+// persistent small-batch tick runs this stage on the lower half of its 512-thread workgroups)
+__device__ __forceinline__ float block_sum_256_t(float v, float *scratch, int t, bool act) {
+    if (act) scratch[t] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = 128; s > 0; s >>= 1) {
+        if (act && t < s) scratch[t] = scratch[t] + scratch[t + s];
+        __syncthreads();
+    }
+    const float r = scratch[0];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float l1_sum_t(const float *d2, int n, float trunc, float *scratch, int t, bool act) {
+    float s = 0.f;
+    for (int i = act ? t : n; i < n; i += 256) {
+        const float v = d2[i];
+        s += (v >= trunc) ? 0.f : sqrtf(v);
+    }
+    return block_sum_256_t(s, scratch, t, act);
+}
+__device__ __forceinline__ float sq_sum_t(const float *x, const float *tt, int K, float *scratch, int t, bool act) {
+    float s = 0.f;
+    for (int k = act ? t : K; k < K; k += 256) {
+        const float e0 = x[3 * k] - tt[3 * k], e1 = x[3 * k + 1] - tt[3 * k + 1], e2 = x[3 * k + 2] - tt[3 * k + 2];
+        s += fmaf(e2, e2, fmaf(e1, e1, e0 * e0));
+    }
+    return block_sum_256_t(s, scratch, t, act);
+}
+// One virtual 256-thread block of the loss stage: vb < nvb - 1 the gradient of 256 warped points, vb == nvb - 1 loss + decision.
+// t: index among the block's 256 active threads; act = false: a thread that only takes part in the barriers.
+__device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, int b, int vb, int nvb, int t, bool act, LossSmem &sm_) {
+    float *red = sm_.red, *rows = sm_.rows;
+    int *cnt = sm_.cnt, *start = sm_.start, *order = sm_.order;
     PT_INIT;
     PT_DECL;
     const ndp_pair_state st = e.state[parity * e.B + b];
     ndp_pair_state *nst = e.state + (size_t)(parity ^ 1) * e.B + b;
     if (st.level >= e.m) {
-        if (blockIdx.x == gridDim.x - 1 && t == 0) { ndp_pair_state c = st; c.decision = NDP_DEC_IDLE; *nst = c; }
+        if (vb == nvb - 1 && t == 0 && act) { ndp_pair_state c = st; c.decision = NDP_DEC_IDLE; *nst = c; }
         return;
     }
     const ndp_pair_geom gm = e.geom[b];
@@ -1555,19 +1591,19 @@ k_eng_loss(ndp_engine e, int parity) {
     const bool use_reg = e.w_reg > 0.f && hcl.nonrig;
     const float *hrec = e.heads + (size_t)b * e.n_cap * NDP_HROW;
 
-    if (blockIdx.x == gridDim.x - 1) {                 // the extra workgroup of the pair: loss + decision, concurrently with the gradient workgroups
+    if (vb == nvb - 1) {                 // the extra workgroup of the pair: loss + decision, concurrently with the gradient workgroups
         float loss = 0.f;
         PT(0);
-        if (gm.K > 0) loss = sq_sum(x_out, ldmk_t, gm.K, red) * (1.0f / (float)gm.K);
+        if (gm.K > 0) loss = sq_sum_t(x_out, ldmk_t, gm.K, red, t, act) * (1.0f / (float)gm.K);
         if (use_cd) {
             float sx = 0.f;
             if (rows_final) {
-                for (int i = t; i < gm.S; i += 256) {
+                for (int i = act ? t : gm.S; i < gm.S; i += 256) {
                     const float v = e.d2x[(size_t)b * e.n_cap + i];
                     sx += (v >= e.trunc) ? 0.f : sqrtf(v);
                 }
             } else {
-                for (int i0 = t; i0 < gm.S; i0 += 2 * 256) {                 // same per-thread order as one source at a time
+                for (int i0 = act ? t : gm.S; i0 < gm.S; i0 += 2 * 256) {                 // same per-thread order as one source at a time
                     int ii[2];
                     NnPart r[2];
 #pragma unroll
@@ -1579,25 +1615,25 @@ k_eng_loss(ndp_engine e, int parity) {
                 }
             }
             PT(1);
-            sx = block_sum_256(sx, red);
+            sx = block_sum_256_t(sx, red, t, act);
             PT(2);
-            const float sy = l1_sum(d2y, gm.T, e.trunc, red);
+            const float sy = l1_sum_t(d2y, gm.T, e.trunc, red, t, act);
             PT(3);
             const float lcd = sx / (float)gm.S + sy / (float)gm.T;
             loss = gm.K > 0 ? loss + e.w_cd * lcd : lcd;
         }
         if (use_reg) {                                   // registration.py:216-220: + w_reg * BCELoss(nonrigidity, 0)
             float acc = 0.f;
-            for (int i = t; i < n; i += 256) {
+            for (int i = act ? t : n; i < n; i += 256) {
                 const float nr = 1.0f / (1.0f + expf(-hrec[(size_t)i * NDP_HROW + hcl.row_nr]));
                 float l1 = logf(1.0f - nr);
                 if (l1 < -100.0f) l1 = -100.0f;
                 acc += -l1;
             }
-            acc = block_sum_256(acc, red);
+            acc = block_sum_256_t(acc, red, t, act);
             loss = loss + e.w_reg * (acc * (1.0f / (float)n));
         }
-        if (t == 0) {
+        if (t == 0 && act) {
             int bc = st.break_counter;
             double lp = st.loss_prev;
             bool stop = false;
@@ -1640,21 +1676,21 @@ k_eng_loss(ndp_engine e, int parity) {
         return;
     }
     // ---- gradient of the loss wrt the warped points of this workgroup
-    const int p = blockIdx.x * 256 + t;
-    if (blockIdx.x * 256 >= n) return;
+    const int p = act ? vb * 256 + t : e.n_cap;                          // (an inactive thread owns no point)
+    if (vb * 256 >= n) return;
     float *dO_row = e.dO + ((size_t)b * e.n_cap + p) * NDP_NHMAX;
     float w[3] = {0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f};
     if (p < n) { w[0] = x_out[3 * p]; w[1] = x_out[3 * p + 1]; w[2] = x_out[3 * p + 2]; }
     const int i_self = p - gm.K;                     // sample index (negative for landmarks)
     // Every phase below is a chain of 1-2 us global round trips (tools/phase_timing.py), so what can be requested now is: the
     // chunk's nearest-source indices (local point of target c0 + t + 256 k, -1: not ours) travel with the row partials.
-    const bool scatter = use_cd && blockIdx.x * 256 + 255 >= gm.K;      // workgroup holds at least one sample
-    const int i_lo = (int)blockIdx.x * 256 - gm.K;                      // sample index of thread 0
+    const bool scatter = use_cd && vb * 256 + 255 >= gm.K;      // workgroup holds at least one sample
+    const int i_lo = vb * 256 - gm.K;                      // sample index of thread 0
     int li[LG_CHUNK / 256];
 #pragma unroll
     for (int k = 0; k < LG_CHUNK / 256; ++k) {
         const int j = t + 256 * k;
-        li[k] = scatter && j < gm.T ? idx_y[j] - i_lo : -1;
+        li[k] = scatter && act && j < gm.T ? idx_y[j] - i_lo : -1;
     }
     if (p < gm.K) {
         const float invK = 1.0f / (float)gm.K;
@@ -1689,11 +1725,11 @@ k_eng_loss(ndp_engine e, int parity) {
 #pragma unroll
                 for (int k = 0; k < LG_CHUNK / 256; ++k) {
                     const int j = t + 256 * k;
-                    li[k] = j < cn ? idx_y[c0 + j] - i_lo : -1;
+                    li[k] = act && j < cn ? idx_y[c0 + j] - i_lo : -1;
                 }
             }
             __syncthreads();
-            cnt[t] = 0;
+            if (act) cnt[t] = 0;
             __syncthreads();
             // pass 1: count
 #pragma unroll
@@ -1703,18 +1739,18 @@ k_eng_loss(ndp_engine e, int parity) {
             PT(1);
             // exclusive scan of cnt -> start (Hillis-Steele over 256 entries)
             const int mine = cnt[t];
-            start[t] = mine;
+            if (act) start[t] = mine;
             __syncthreads();
 #pragma unroll
             for (int d = 1; d < 256; d <<= 1) {
                 const int v = t >= d ? start[t - d] : 0;
                 __syncthreads();
-                start[t] += v;
+                if (act) start[t] += v;
                 __syncthreads();
             }
             const int my_start = start[t] - mine;
             __syncthreads();
-            start[t] = my_start;                                          // becomes the fill cursor
+            if (act) start[t] = my_start;                                 // becomes the fill cursor
             __syncthreads();
             PT(2);
             // pass 2: fill
@@ -1775,15 +1811,21 @@ k_eng_loss(ndp_engine e, int parity) {
         for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o));
         float *wm = rows;                                // (every thread is done with its row; one atomic per workgroup, not per wave)
         __syncthreads();
-        if ((t & 63) == 0) wm[t >> 6] = amax;
+        if (act && (t & 63) == 0) wm[t >> 6] = amax;
         __syncthreads();
-        if (t == 0) {
+        if (t == 0 && act) {
             const float m4 = fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]));
             if (m4 > 0.f) atomicMax(e.gmax + b, __float_as_uint(m4));      // non-negative floats order like their bit patterns
         }
     }
     PT(5);
     PT_FLUSH(36);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_loss(ndp_engine e, int parity) {
+    __shared__ LossSmem sm_;
+    eng_loss_body(e, parity, blockIdx.y, blockIdx.x, gridDim.x, threadIdx.x, true, sm_);
 }
 
 // backward of the live tiles of every pair that takes an Adam step this tick (two launches, see bwd2/bwd1)
@@ -1839,14 +1881,8 @@ k_eng_bwd1(ndp_engine e, int parity) {
 // fold the G partial gradients in index order, Adam step, level hand-over (fresh Adam state).
 // (Four parameters per thread on 16-byte accesses: no faster at 128 pairs -- 0.0305 against 0.0315 ms -- and TWICE as slow at batch 1,
 //  where the G = 32 partials are folded by a quarter of the threads: 0.023 against 0.012 ms.  One parameter per thread it stays.)
-extern "C" __global__ void __launch_bounds__(256)
-k_eng_update(ndp_engine e, int parity) {
-    const int b = blockIdx.y;
-    const ndp_pair_state ns = e.state[(size_t)(parity ^ 1) * e.B + b];      // written by k_eng_bwd this tick
-    if (ns.decision == NDP_DEC_IDLE) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const ndp_layer_desc dl = desc_at_level(e.desc, ns.step_level);
-    if (i >= e.P) return;
+// parameter i of pair b: fold, Adam, hand-over (the whole update stage is this, for every i < P)
+__device__ __forceinline__ void eng_update_param(const ndp_engine &e, int b, const ndp_pair_state &ns, const ndp_layer_desc &dl, int i) {
     float *m = e.adam_m + (size_t)b * e.p_stride, *v = e.adam_v + (size_t)b * e.p_stride;
     if (i >= ndp_param_count(&dl)) {                     // level 0 has no gate row: nothing to step, keep moments clean
         if (ns.decision != NDP_DEC_STEP) { m[i] = 0.f; v[i] = 0.f; }
@@ -1864,6 +1900,17 @@ k_eng_update(ndp_engine e, int parity) {
     }
     if (ns.decision != NDP_DEC_STEP) { m[i] = 0.f; v[i] = 0.f; }             // registration.py:176
 }
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_update(ndp_engine e, int parity) {
+    const int b = blockIdx.y;
+    const ndp_pair_state ns = e.state[(size_t)(parity ^ 1) * e.B + b];      // written by k_eng_loss this tick
+    if (ns.decision == NDP_DEC_IDLE) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= e.P) return;
+    eng_update_param(e, b, ns, desc_at_level(e.desc, ns.step_level), i);
+}
+
+#include "ndp_tick_small.inc"
 
 // ------------------------------------------------------------------------------------------------
 // Neural scene-flow prior baseline (nets.py:256-292): one launch per layer
@@ -2459,7 +2506,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
     // partials per pair); in a mixed configuration they take half the fp32 grid and zero the partials they do not write.
     const dim3 g_fwd8(engine_g8(e), e->B);
-    if (e->gemm_mode < 0 || e->gemm_mode > 255) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1), 64 (the Adam step inside the fused backward)");
+    if (e->gemm_mode < 0 || e->gemm_mode > 511) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1), 64 (the Adam step inside the fused backward)");
     // both backward layers on the splits: ONE launch (k_eng_bwd_f, stage 3; stage 4 launches nothing) unless bit 16 asks for the two round-3 kernels
     const bool bwd_fused = (e->gemm_mode & 6) == 6 && !(e->gemm_mode & 16);
     if (bwd_fused) if (int rc = set_smem((const void *)k_eng_bwd_f, kSmemBwdFBytes)) return rc;
@@ -2470,6 +2517,22 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     const dim3 g_nn_lat(e->n_cap / 64 + e->t_cap / 64, e->B);
     const dim3 g_upd((e->P + 255) / 256, e->B);
     const dim3 g_loss((e->n_cap + 255) / 256 + 1, e->B);   // + 1: the loss / decision workgroup
+    // MEASURED VARIANT (gemm_mode bit 256, round 4): a handful of resident pairs run the whole chunk of ticks as ONE persistent launch whose
+    // stages are separated by pair barriers (csrc/ndp_tick_small.inc) -- bitwise the launches, but 115 us per tick against 74 at batch 1:
+    // five agent-scope release / acquire pairs per tick (the per-XCD L2s are not coherent: every release writes an L2 back) cost more
+    // than six kernel boundaries.  Needs: fused split backward, latency-shape NN, one tile per workgroup, every workgroup resident.
+    // one tile per level-kernel workgroup and few of them: the per-point warp rides in the forward launch (ndp_fwd_split.inc)
+    const bool warp_in_fwd = (e->gemm_mode & 1) && (int)g_fwd8.x == e->n_cap / NDP_TILE && e->B * (int)g_fwd8.x <= 256;
+    const bool persistent = !ev && stage_lo == 0 && stage_hi == NDP_TICK_KERNELS - 1 && bwd_fused && (e->gemm_mode & 1) &&
+                            (e->gemm_mode & 256) && !(e->gemm_mode & (32 | 64)) && (!nn || e->nn_mode == 1) && e->G == e->n_cap / NDP_TILE &&
+                            e->B * e->G <= 256 && n_ticks > 0;
+    if (persistent) {
+        if (int rc = set_smem((const void *)k_eng_tick_small, kSmemTickSmallBytes)) return rc;
+        HIP_TRY(hipMemsetAsync(e->gmax + e->B, 0, sizeof(unsigned) * e->B, s), "pair barrier counters");
+        hipLaunchKernelGGL(k_eng_tick_small, dim3(e->G, e->B), dim3(512), kSmemTickSmallBytes, s, *e, tick0, n_ticks);
+        HIP_TRY(hipGetLastError(), "persistent tick launch");
+        return 0;
+    }
     for (int k = 0; k < n_ticks; ++k) {
         const int parity = (tick0 + k) & 1;
         hipEvent_t *q = ev ? ev + (size_t)k * (NDP_TICK_KERNELS + 1) : nullptr;
@@ -2479,8 +2542,8 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         NDP_EV();
         if (!NDP_ST(0)) {}
         else if (e->gemm_mode & 1) {
-            hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity);
-            hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
+            hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity, warp_in_fwd ? 1 : 0);
+            if (!warp_in_fwd) hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
         }
         else hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         NDP_EV();

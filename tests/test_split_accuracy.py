@@ -302,3 +302,38 @@ def test_adam_step_inside_the_fused_backward_is_bitwise_the_update_launch(dev):
         assert torch.equal(a.adam_m, b.adam_m) and torch.equal(a.adam_v, b.adam_v), tick
         assert [(s.level, s.iter, s.adam_t) for s in a.read_states()] == [(s.level, s.iter, s.adam_t) for s in b.read_states()]
     assert max(s.level for s in engs[0].read_states()) >= 1                       # the run crossed a hand-over
+
+
+@pytest.mark.parametrize("tag,K", [("se3aa", 0), ("sim3eu", 0), ("se3aa", 40)])
+def test_persistent_small_batch_tick_is_bitwise_the_launches(dev, tag, K):
+    """gemm_mode bit 256 (a measured variant, slower than the launches: DESIGN section 0): a handful of resident pairs run their ticks as
+    ONE persistent launch per chunk (k_eng_tick_small: the stage bodies of the engine kernels separated by pair barriers with
+    agent-scope release / acquire).  Same code per stage, same order: parameters,
+    Adam moments, warped points, nearest-neighbour results and pair states are BITWISE equal after every chunk of a run that crosses
+    level hand-overs with the early stop on -- chunks of 1, 3 and 5 ticks, clouds that do not fill their last tile, landmarks."""
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    pyr = seeded_pyramid(5, m=3, **VARIANTS[tag])
+    for lvl in range(3):
+        scale_heads(pyr, lvl, 20.0)
+    engs = []
+    for mode in (7 | 256, 7):
+        cfg = OptConfig(m=3, iters=6, early_stop=True, w_cd=1.0 if K == 0 else 0.5)
+        eng = BatchedEngine(pyr.descs[0], cfg, 3, n_cap=640, t_cap=640, device=dev, gemm_mode=mode, nn_mode=1)
+        assert eng.G == 10
+        g = torch.Generator().manual_seed(9)
+        for b, S in enumerate((600, 333, 64)):
+            src = (torch.rand(S + K, 3, generator=g) - 0.5).contiguous()
+            tgt = ((torch.rand(500, 3, generator=g) - 0.5) * 1.05).contiguous()
+            ldmk = None if K == 0 else (src[:K] + 0.01).contiguous()
+            eng.load(b, src, K, S, ldmk, tgt, pyr.store)
+        engs.append(eng)
+    for chunk in (1, 3, 5, 1, 5, 5):
+        for eng in engs:
+            eng.run_ticks(chunk)
+        torch.cuda.synchronize()
+        a, b = engs
+        for name in ("params", "adam_m", "adam_v", "pts", "d2x", "d2y", "idx_x", "idx_y", "dO", "heads"):
+            assert torch.equal(getattr(a, name), getattr(b, name)), (name, chunk)
+        sa, sb = a.read_states(), b.read_states()
+        assert [(s.level, s.iter, s.adam_t, s.total_steps, s.loss) for s in sa] == [(s.level, s.iter, s.adam_t, s.total_steps, s.loss) for s in sb]
+    assert max(s.level for s in engs[0].read_states()) >= 1
