@@ -1455,9 +1455,8 @@ __device__ __forceinline__ void nn1_body(const float *xs, int S, const float *ys
 
 // few pairs resident: blockIdx.x < ceil(n_cap/64): 64 source samples -> targets;  else 64 targets -> source samples.
 // Writes the final d2x / idx_x / d2y / idx_y (no partials): e.nn_mode = 1 tells the loss kernel to read them.
-extern "C" __global__ void __launch_bounds__(256)
-k_eng_nn_lat(ndp_engine e, int parity) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+template <int NW>
+__device__ __forceinline__ void eng_nn_lat_stage(const ndp_engine &e, int parity, float *sm) {
     const int b = blockIdx.y;
     const ndp_pair_state st = e.state[parity * e.B + b];
     if (st.level >= e.m) return;
@@ -1469,13 +1468,25 @@ k_eng_nn_lat(ndp_engine e, int parity) {
     if ((int)blockIdx.x < bx) {
         const int qb = blockIdx.x * 64;
         if (qb >= gm.S) return;
-        nn_lat_body(xw, gm.S, y, gm.T, e.d2x + (size_t)b * e.n_cap, e.idx_x + (size_t)b * e.n_cap, qb, sm);
+        nn_lat_body<NW>(xw, gm.S, y, gm.T, e.d2x + (size_t)b * e.n_cap, e.idx_x + (size_t)b * e.n_cap, qb, sm);
     } else {
         const int qb = (blockIdx.x - bx) * 64;
         int *iy = e.idx_y + (size_t)b * e.t_cap;
-        if (qb < gm.T) nn_lat_body(y, gm.T, xw, gm.S, e.d2y + (size_t)b * e.t_cap, iy, qb, sm);
+        if (qb < gm.T) nn_lat_body<NW>(y, gm.T, xw, gm.S, e.d2y + (size_t)b * e.t_cap, iy, qb, sm);
         if (threadIdx.x < 64 && qb + (int)threadIdx.x >= gm.T && qb + (int)threadIdx.x < e.t_cap) iy[qb + threadIdx.x] = -1;
     }
+}
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_nn_lat(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    eng_nn_lat_stage<4>(e, parity, sm);
+}
+// the same with eight waves per 64 queries (each scans an eighth of every stage): what the engine launches (round 4) -- at batch 1
+// the stage is one workgroup's latency, 10.7 -> us (the fold over the waves keeps the lowest index: same results)
+extern "C" __global__ void __launch_bounds__(512)
+k_eng_nn_lat8(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    eng_nn_lat_stage<8>(e, parity, sm);
 }
 
 extern "C" __global__ void __launch_bounds__(256)
@@ -1891,7 +1902,15 @@ __device__ __forceinline__ void eng_update_param(const ndp_engine &e, int b, con
     if (ns.decision != NDP_DEC_ADVANCE) {
         const float *gp = e.gpart + (size_t)b * e.G * e.p_stride;
         float g = gp[i];
-        for (int k = 1; k < e.G; ++k) g += gp[(size_t)k * e.p_stride + i];
+        int k = 1;
+        for (; k + 8 <= e.G; k += 8) {                               // eight partials requested together, added in index order (batch 1 folds 32)
+            float q[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) q[u] = gp[(size_t)(k + u) * e.p_stride + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g += q[u];
+        }
+        for (; k < e.G; ++k) g += gp[(size_t)k * e.p_stride + i];
         float *p = e.params + ((size_t)b * e.m + ns.step_level) * e.p_stride;
         float pi = p[i], mi = m[i], vi = v[i];
         adam_update(pi, g, mi, vi, e.adam_w1, e.adam_b2, e.adam_w2, e.adam_tab[2 * ns.step_t],
@@ -2548,6 +2567,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         else hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         NDP_EV();
         if (!NDP_ST(1)) {}
+        else if (nn && e->nn_mode == 1 && !(e->gemm_mode & 128)) hipLaunchKernelGGL(k_eng_nn_lat8, g_nn_lat, dim3(512), (3 * NN_STAGE + 2 * 512) * 4, s, *e, parity);
         else if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);
         else if (nn_mx8) hipLaunchKernelGGL(k_eng_nn_mx8, dim3((e->t_cap + 511) / 512, e->B), dim3(512), nn2_lds_floats(e->n_cap, 8) * 4, s, *e, parity);
         else if (nn && e->nn_mode == 2) hipLaunchKernelGGL(k_eng_nn_mx, g_nn, blk, nn2_lds_floats(e->n_cap) * 4, s, *e, parity);
