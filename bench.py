@@ -97,7 +97,7 @@ def stage_kernels(gemm_mode, nn_mode):
     """The launches behind each of the six tick stages (N.TICK_KERNELS order) for an engine's modes."""
     fused = bwd_fused(gemm_mode)
     return {"k_eng_fwd": ["k_eng_fwd8", "k_eng_warp"] if gemm_mode & 1 else ["k_eng_fwd"],
-            "k_eng_nn": [{0: "k_eng_nn", 1: "k_eng_nn_lat", 2: "k_eng_nn_mx" if gemm_mode & 128 else "k_eng_nn_mx8"}[nn_mode]],
+            "k_eng_nn": [{0: "k_eng_nn", 1: "k_eng_nn_lat" if gemm_mode & 128 else "k_eng_nn_lat8", 2: "k_eng_nn_mx" if gemm_mode & 128 else "k_eng_nn_mx8"}[nn_mode]],
             "k_eng_loss": ["k_eng_loss"],
             "k_eng_bwd2": ["k_eng_bwd_f"] if fused else (["k_eng_bwd2_8"] if gemm_mode & 4 else ["k_eng_bwd2"]),
             "k_eng_bwd1": [] if fused else (["k_eng_bwd1_8"] if gemm_mode & 2 else ["k_eng_bwd1"]),
