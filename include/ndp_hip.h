@@ -260,6 +260,10 @@ typedef struct ndp_engine {
                                         by powers of two -- activations and weights beyond 1023 saturate there); bit 16: as the two
                                         launches k_eng_bwd2_8 + k_eng_bwd1_8 instead; bit 32 (tests): the fused launch also writes
                                         dz1 over the h2 plane of `act`, where the two-launch form leaves it.
+                                        Measured variants kept behind bits: 64 the Adam step by the last-arriving
+                                        backward workgroup of a pair (no k_eng_update launch; gmax must then be [2 B]); 128 the 4-wave
+                                        shapes of the nearest-neighbour kernels; 256 a persistent one-launch tick for a handful of
+                                        resident pairs (k_eng_tick_small; gmax [2 B]) -- all bitwise the default, all slower.
                                         nn_mode 0: one-pass kernel, distances on the vector pipe; 2: the same on the bf16 matrix pipe
                                         with exact re-evaluation (bit-identical, needs ndp_engine_nn_matrix_fits(n_cap)); 1: latency
                                         shape -- two passes in 64-query workgroups, S/64 + T/64 of them per pair -- for a handful of
