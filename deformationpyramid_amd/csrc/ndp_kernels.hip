@@ -50,11 +50,13 @@ __shared__ unsigned long long pt_acc[12];                 // per-workgroup accum
 #define PT_TID 0                                          /* the stamping thread (wave-specialised experiments look at other waves too) */
 #endif
 #define PT_DECL unsigned long long pt_last = __builtin_readcyclecounter()
+/* the branch is wave-uniform and the counter scalar: pt_last lives in two SGPRs (a per-thread copy cost the register-capped kernels \
+   two VGPRs over their whole body -- the fused backward's timing build spilled) */                                               \
 #define PT(id)                                                                  \
     do {                                                                        \
-        if (threadIdx.x == PT_TID) {                                                 \
+        if (__builtin_amdgcn_readfirstlane((int)threadIdx.x) == PT_TID) {       \
             const unsigned long long pt_now = __builtin_readcyclecounter();     \
-            pt_acc[(id) % 12] += pt_now - pt_last;                              \
+            if (threadIdx.x == PT_TID) pt_acc[(id) % 12] += pt_now - pt_last;   \
             pt_last = pt_now;                                                   \
         }                                                                       \
     } while (0)
@@ -63,6 +65,11 @@ __shared__ unsigned long long pt_acc[12];                 // per-workgroup accum
 #define PT_FLUSH(base)
 #define PT_DECL
 #define PT(id)
+#endif
+#ifdef NDP_PHASE_TIMING_FINE                              /* stamps inside a barrier interval (they pin the schedule around them) */
+#define PTF(id) PT(id)
+#else
+#define PTF(id)
 #endif
 
 // ------------------------------------------------------------------------------------------------

@@ -65,6 +65,8 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
     eng.run_stages(0, 2)                                      # forward, nearest neighbours, loss / dL/dx'
     torch.cuda.synchronize()
     out["act_fwd"] = eng.act[0].cpu().clone()                 # h0, h1, h2
+    if (mode & 6) == 6 and not mode & 16:                     # the fused backward reads h1 as the forward's plane image, not as fp32 rows
+        out["act_fwd"][1] = _decode_h1_image(out["act_fwd"][1])
     out["heads"] = eng.heads[0].cpu().clone()
     out["dO"] = eng.dO[0].cpu().clone()
     eng.run_stages(3, 3)                                      # bwd2
@@ -76,6 +78,26 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
     out["g_all"] = eng.gpart[0].double().sum(0)[:P].cpu().clone()
     eng.run_stages(5, 5)
     torch.cuda.synchronize()
+    return out
+
+
+def _decode_h1_image(act1):
+    """The h1 plane image the split forward leaves for the FUSED backward (gemm_mode 7): per 64-point tile 32 KB -- the footprint of the
+    fp32 rows it replaces -- holding two fp16 planes [64][128], hi = fp16(2^6 h1) and lo = fp16(2^6 h1 - hi), each row's sixteen
+    16-byte granules XOR-swizzled (ndp_fwd_split.inc: bf_swz).  -> [rows][128] float32 (hi + lo carries 22 bits: exact in fp32)."""
+    rows = act1.shape[0] // 64 * 64
+    img = act1[:rows].contiguous().view(torch.float16).view(rows // 64, 2, 64, 128).float()
+    p = torch.arange(64)
+    g = torch.tensor([0, 2, 3, 1])
+    swz = ((((p & 3) << 2) | g[(p >> 2) & 3]) << 3)[:, None]
+    idx = (torch.arange(128)[None, :] ^ swz).expand(rows // 64, 2, 64, 128)
+    planes = torch.gather(img, 3, idx)
+    out = torch.full_like(act1, float("nan"))
+    val = (planes[:, 0] + planes[:, 1]) / 64.0
+    # the ReLU mask is the HI plane's sign (hi is kept >= 2^-24 wherever h1 > 0; for 2^6 h1 < 2^-25 lo then rounds to -2^-24 and the
+    # sum to zero): such an element decodes to a positive value below everything else
+    val = torch.where((planes[:, 0] > 0) & (val <= 0), torch.full_like(val, 2.0 ** -40), val)
+    out[:rows] = val.reshape(rows, 128)
     return out
 
 
@@ -212,14 +234,20 @@ def test_relu_masks_of_the_split_backward_see_activations_below_fp16s_range(dev)
 
 
 def test_activations_beyond_fp16s_range_saturate(dev):
-    """fp16 ends at 65504.  An activation beyond it enters the next contraction as 65504 (the fp32 copy the backward reads keeps its
-    value), a weight likewise: the results are then no longer the fp32 chain's, but they stay finite -- no inf, no NaN anywhere in
-    the tick.  (This network's activations are O(1): its inputs are sines and cosines, its weights O(0.1).)"""
-    r = _run_tick_by_stages(dev, "se3aa", 7, 2000, 2000, 0, 20.0, G=2, b1=1.0e5)
-    assert float(r["act_fwd"][1, :2000].min()) > 65504.0                         # every h1 is out of range
-    for k in ("act_fwd", "heads", "dO", "dz1"):
-        assert bool(torch.isfinite(r[k][..., :2000, :] if r[k].dim() == 3 else r[k][:2000]).all()), k
-    assert bool(torch.isfinite(r["g_all"]).all())
+    """fp16 ends at 65504.  An operand beyond it enters a contraction saturated: layer 0's output at 65504; h1 and every activation
+    and weight of the fused backward, which are split as 2^6 x, at 65504 / 64 = 1023.5 (the h1 plane image IS that split; the fp32 h1
+    rows the two-launch backward reads keep their value).  The results are then no longer the fp32 chain's, but they stay finite -- no
+    inf, no NaN anywhere in the tick.  (This network's activations are O(1): its inputs are sines and cosines, its weights O(0.1).)"""
+    for mode in (7, 23):
+        r = _run_tick_by_stages(dev, "se3aa", mode, 2000, 2000, 0, 20.0, G=2, b1=1.0e5)
+        h1 = r["act_fwd"][1, :2000]
+        if mode == 7:
+            assert float(h1.min()) == float(h1.max()) == 65504.0 / 64.0         # every h1 is out of range: the image holds the bound
+        else:
+            assert float(h1.min()) > 65504.0
+        for k in ("act_fwd", "heads", "dO", "dz1"):
+            assert bool(torch.isfinite(r[k][..., :2000, :] if r[k].dim() == 3 else r[k][:2000]).all()), (mode, k)
+        assert bool(torch.isfinite(r["g_all"]).all())
 
 
 def test_h0_is_recomputed_by_the_split_backward_not_read_back(dev):
@@ -268,7 +296,10 @@ def test_fused_backward_agrees_with_the_two_launch_backward(dev, tag, level):
     float64 -- every gradient tensor within 2e-6 of its own scale -- not bit equality.  Stage 4 of the fused tick launches nothing."""
     a = _run_tick_by_stages(dev, tag, 7, 2000, 2000, level, 20.0, G=2)          # fused (+ dz1 dump)
     b = _run_tick_by_stages(dev, tag, 7 | 16, 2000, 2000, level, 20.0, G=2)     # two launches
-    assert torch.equal(a["dO"], b["dO"]) and torch.equal(a["act_fwd"], b["act_fwd"])
+    assert torch.equal(a["dO"], b["dO"]) and torch.equal(a["act_fwd"][0], b["act_fwd"][0]) and torch.equal(a["act_fwd"][2], b["act_fwd"][2])
+    # h1: the fused backward's forward leaves the split it fed to layer 2 (22 bits of 2^6 h1, as a plane image), the other the fp32 value
+    h1a, h1b = a["act_fwd"][1, :2000].double(), b["act_fwd"][1, :2000].double()
+    assert bool(((h1a - h1b).abs() <= 2.0 ** -21 * h1b.abs() + 2.0 ** -31).all()) and bool(((h1a > 0) == (h1b > 0)).all())
     assert torch.equal(a["g_bwd2"], a["g_all"])                                  # the fused stage 3 is the whole backward
     ka, kb = _kernel_outputs(a), _kernel_outputs(b)
     for k in ("dWh", "dbh", "dW2", "db2", "dz1", "dW1", "db1", "dW0", "db0"):

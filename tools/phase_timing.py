@@ -98,10 +98,12 @@ if eng.nn_mode == 2:
         print(f"   {nm:58s} {buf[64 + i] / wgs:9.0f}  {100.0 * buf[64 + i] / max(tot, 1):5.1f} %")
 FUSED = (eng.gemm_mode & 6) == 6 and not (eng.gemm_mode & 16)
 if FUSED:
-    nmf = ["top barrier (incl. wait for the requested rows)", "stage 1: h1 split, dbh, encoding rows -> LDS", "-",
-           "stage 2 (no barrier before it): dWh, dz2 chain + split", "barrier", "h0 recompute + split, wgrad2 (24 MFMA 32x32x16)",
-           "dgrad2 (48 MFMA 16x16x32) + mask + dz1 split -> planes", "barrier", "wgrad1 (24 MFMA) + the next tile's requests",
-           "dgrad1 (48 MFMA, swapped) + mask + [dW0 | db0]", "prologue: weight slices, staging (once per workgroup)", "tail: partial stores, bias sums (once per workgroup)"]
+    # default: three stamps per tile, one after each barrier (any stamp INSIDE a barrier interval pins the schedule of this
+    # register-capped kernel and its timing build spills); -DNDP_PHASE_TIMING_FINE adds the inner ones (distorted: read with care)
+    nmf = ["stage 4 (wgrad1, swapped dgrad1, [dW0|db0], next tile's requests) + wait for the h2 rows + top barrier", "(fine) stage 1",
+           "-", "(fine) stage 2", "stages 1-2 (small rows; dWh, dz2 chain + split) + wait for the h1 image + barrier", "(fine) h0 recompute, wgrad2",
+           "(fine) dgrad2 + mask + dz1 split", "stage 3 (h0 recompute + split, wgrad2, dgrad2 + mask + dz1 split) + barrier", "(fine) wgrad1",
+           "(fine) dgrad1", "prologue: weight slices, staging (once per workgroup)", "tail: partial stores, bias sums (once per workgroup)"]
     tot = sum(buf[24 + i] for i in range(12))
     print(f"bwd_f (fused): {tot / tiles:.0f} cycles per tile (thread 0 wall)")
     for i, nm in enumerate(nmf):
