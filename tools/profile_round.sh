@@ -46,4 +46,12 @@ NDP_GEMM_MODE=23 bash $R/tools/pmc_traffic.sh 128 8 > $O/${TAG}_hbm_traffic_2lau
 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_pmc.json
 NDP_GEMM_MODE=23 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_2launch_pmc.json
 NDP_GEMM_MODE=0 NDP_NN_MODE=0 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_bitwise_pmc.json
+bash $R/tools/pmc_mix.sh 256 12 > /dev/null 2>&1; cp $O/pmc_mix.json $O/${TAG}_instruction_mix_pmc.json 2> /dev/null
+# the two microbenchmarks behind the kernels' cost model: the matrix and the vector pipe of a SIMD side by side (they are not), issue
+# cost of the vector instructions the level kernels are made of
+for m in coexec valu_rates; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$m $R/tools/experiments/micro/$m.hip > /dev/null 2>&1 && /tmp/$m > $O/${TAG}_micro_$m.txt 2>&1
+done
+python $R/tools/latency_bench.py 5 > $O/${TAG}_latency_persistent_ab.txt 2>&1
+for k in k_eng_fwd8 k_eng_bwd_f k_eng_nn_mx8; do python $R/tools/isa_cost.py $k; done > $O/${TAG}_isa_issue_cost.txt 2>&1
 ls -la $O | grep ${TAG}_
