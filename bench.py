@@ -161,9 +161,9 @@ def roofline_report(model, pairs, B, config):
 
 
 ARITH_TEXT = {0: "fp32 MFMA, bitwise the oracle's fma chain",
-              7: "128x128 contractions of the three level kernels as two-way fp16 splits (x = hi + 2^-11 lo, three partial products, gradient "
-                 "operands scaled by a power of two per pair) on the fp16 MFMA, fp32 accumulate: closer to float64 than the fp32 chain "
-                 "(tests/test_split_accuracy.py), not bitwise the chain"}
+              7: "128x128 contractions of the level kernels as two-way fp16 splits (2^k x = hi + lo, three partial products into one fp32 "
+                 "accumulator; activations and weights scaled by 2^6, gradient operands by a power of two per pair) on the fp16 MFMA: "
+                 "as close to float64 as the fp32 chain (0.5-2x its RMS error per tensor, tests/test_split_accuracy.py), not bitwise the chain"}
 # `dtype` of the line: fp32 storage, fp32 accumulation and fp32-level accuracy in both arithmetics; the split one says how its products are formed
 DTYPE_TEXT = {0: "f32", 7: "f32 (fp16x2-split contractions, fp32 accumulate)"}
 NN_TEXT = {0: "one pass, distances on the vector pipe", 1: "latency shape (two passes, 64-query workgroups)",

@@ -242,7 +242,11 @@ typedef struct ndp_engine {
     float *params;                   /* [B][m][p_stride]                                        */
     float *gpart;                    /* [B][G][p_stride]                                        */
     float *adam_m, *adam_v;          /* [B][p_stride]                                           */
-    float *act;                      /* [B][3][n_cap][128]                                      */
+    float *act;                      /* [B][3][n_cap][128] fp32 rows of h0, h1, h2 -- except under the default gemm_mode 7 (fused
+                                        split backward), where plane 1 holds h1 per 64-point tile as a PLANE IMAGE of the same size:
+                                        two [64][128] fp16 planes hi = fp16(2^6 h1) | lo = fp16(2^6 h1 - hi), rows of 256 bytes with
+                                        their 16-byte granules XOR-swizzled (csrc/ndp_fwd_split.inc: bf_swz) -- the backward's LDS
+                                        layout, written by the forward and pulled in by LDS-DMA                 */
     float *heads;                    /* [B][n_cap][NDP_HROW]                                    */
     float *d2x; int *idx_x;          /* [B][n_cap]                                              */
     float *d2y; int *idx_y;          /* [B][t_cap]                                              */
@@ -250,11 +254,12 @@ typedef struct ndp_engine {
     float *dO;                       /* [B][n_cap][16] mlp_scale * dL/d(head outputs), this tick */
     float *nn_row;                   /* one-pass 1-NN row partials, B x ndp_engine_nn_workspace() floats (NULL if w_cd == 0) */
     int nn_mode, gemm_mode;          /* gemm_mode 0: level kernels on the fp32 MFMA, bitwise the oracle's fma chain.  Mask 1 forward,
-                                        2 bwd1, 4 bwd2: their 128 x 128 contractions from two-way fp16 splits (hi + 2^-11 lo, three
-                                        products, fp32 accumulate) on the 16-bit MFMA -- fp32-level accuracy, not bitwise the chain
+                                        2 bwd1, 4 bwd2: their 128 x 128 contractions from two-way fp16 splits (x' = hi + lo of operands
+                                        pre-scaled by a power of two, three products, fp32 accumulate; the two-launch backward of bit
+                                        16: hi + 2^-11 lo) on the 16-bit MFMA -- fp32-level accuracy, not bitwise the chain
                                         (csrc/ndp_*_split.inc); 7 is what Registration uses by default.  With 1 | 2 the forward does
                                         not store h0 (act[b][0] is left untouched): the backward recomputes it from the saved
-                                        encoding with the forward's own two MFMAs; bit 8 makes the forward store it all the same
+                                        encoding with the forward's own layer-0 MFMA; bit 8 makes the forward store it all the same
                                         (tests).  With 2 | 4 both backward layers run as ONE launch (k_eng_bwd_f,
                                         csrc/ndp_bwd_fused.inc: dz1 stays in LDS, one accumulator per product on operands pre-scaled
                                         by powers of two -- activations and weights beyond 1023 saturate there); bit 16: as the two
