@@ -53,5 +53,6 @@ for m in coexec valu_rates; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$m $R/tools/experiments/micro/$m.hip > /dev/null 2>&1 && /tmp/$m > $O/${TAG}_micro_$m.txt 2>&1
 done
 python $R/tools/latency_bench.py 5 > $O/${TAG}_latency_persistent_ab.txt 2>&1
+python $R/tools/surface_accuracy.py 8 > $O/${TAG}_surface_accuracy_seeds.txt 2>&1
 for k in k_eng_fwd8 k_eng_bwd_f k_eng_nn_mx8; do python $R/tools/isa_cost.py $k; done > $O/${TAG}_isa_issue_cost.txt 2>&1
 ls -la $O | grep ${TAG}_
