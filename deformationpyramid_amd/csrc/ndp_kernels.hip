@@ -1306,14 +1306,16 @@ __host__ __device__ inline bool nn1_stage_x(int n_cap) { return nn1_lds_floats(n
 
 // nearest target of NS sources (i[0..NS-1]; i < 0: skipped) from the row partials of the live target chunks (strict <: the
 // first chunk keeps ties).  The partials of up to 8 chunks x NS sources are requested together: with one load in flight per
-// thread the fold of S = 8192 x 24 chunks by the loss workgroup was a 0.2 ms latency chain.
+// thread the fold of S = 8192 x 24 chunks by the loss workgroup was a 0.2 ms latency chain.  cstep: the partials are indexed by
+// 256-target chunk; a producer whose workgroups cover 512 targets (k_eng_nn_mx8) writes every SECOND slot only -- cstep = 2.
 template <int NS>
 __device__ __forceinline__ void nn_row_fold_n(const NnPart *rowpart /*[chunks][n_cap]*/, int n_cap, int T, const int (&i)[NS],
-                                              NnPart (&r)[NS]) {
+                                              NnPart (&r)[NS], int cstep = 1) {
 #pragma unroll
     for (int s = 0; s < NS; ++s) { r[s].d2 = INFINITY; r[s].idx = -1; }
     if (!rowpart) return;
-    const int live = (T + NN1_YCH - 1) / NN1_YCH;
+    const int live = ((T + NN1_YCH - 1) / NN1_YCH + cstep - 1) / cstep;
+    n_cap *= cstep;                                                  // (slot c of the producer is chunk c * cstep)
     for (int c0 = 0; c0 < live; c0 += 8) {
         NnPart q[NS][8];
 #pragma unroll
@@ -1330,10 +1332,10 @@ __device__ __forceinline__ void nn_row_fold_n(const NnPart *rowpart /*[chunks][n
                 if (q[s][k].d2 < r[s].d2) r[s] = q[s][k];
     }
 }
-__device__ __forceinline__ NnPart nn_row_fold(const NnPart *rowpart, int n_cap, int T, int i) {
+__device__ __forceinline__ NnPart nn_row_fold(const NnPart *rowpart, int n_cap, int T, int i, int cstep = 1) {
     const int ii[1] = {i};
     NnPart r[1];
-    nn_row_fold_n<1>(rowpart, n_cap, T, ii, r);
+    nn_row_fold_n<1>(rowpart, n_cap, T, ii, r, cstep);
     return r[0];
 }
 
@@ -1537,6 +1539,11 @@ k_nn1_rows(int S, int T, int n_cap, const float *ws_row, float *d2x, int *idx_x)
 }
 
 #include "ndp_nn_matrix.inc"
+// Does the engine's nearest-neighbour stage run as k_eng_nn_mx8 (one workgroup and ONE row partial per 512 targets)?  The launcher and
+// the loss stage's fold of the row partials ask the same question.
+__host__ __device__ inline bool eng_nn_mx8(const ndp_engine &e) {
+    return e.w_cd != 0.f && e.t_cap > 0 && e.nn_mode == 2 && nn2_lds_floats(e.n_cap, 8) * 4 <= 160 * 1024 && !(e.gemm_mode & 128);
+}
 
 // Loss, early-stop decision and dL/dx' for every pair (one launch per tick).
 //   last workgroup of a pair: loss (registration.py:193-212; loss.py:185-258), the stop rule in double
@@ -1604,6 +1611,7 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
     // nearest target of a source: folded here from the one-pass kernel's per-chunk partials (nn_row_fold)
     const NnPart *rowpart = reinterpret_cast<const NnPart *>(e.nn_row) + (size_t)b * nn1_row_chunks(e.t_cap) * e.n_cap;
     const bool rows_final = e.nn_mode == 1;          // latency shape: d2x / idx_x already hold the answer
+    const int rows_cstep = eng_nn_mx8(e) ? 2 : 1;    // the 8-wave matrix-pipe kernel leaves one partial per 512 targets
     const bool use_cd = gm.S > 0 && e.w_cd != 0.f;
     const HeadCfg hcl = make_head_cfg(desc_at_level(e.desc, st.level));
     const bool use_reg = e.w_reg > 0.f && hcl.nonrig;
@@ -1626,7 +1634,7 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
                     NnPart r[2];
 #pragma unroll
                     for (int s = 0; s < 2; ++s) ii[s] = i0 + 256 * s < gm.S ? i0 + 256 * s : -1;
-                    nn_row_fold_n<2>(rowpart, e.n_cap, gm.T, ii, r);
+                    nn_row_fold_n<2>(rowpart, e.n_cap, gm.T, ii, r, rows_cstep);
 #pragma unroll
                     for (int s = 0; s < 2; ++s)
                         if (ii[s] >= 0) sx += (r[s].d2 >= e.trunc) ? 0.f : sqrtf(r[s].d2);
@@ -1718,7 +1726,7 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
         NnPart nx;
         if (rows_final) { nx.d2 = e.d2x[(size_t)b * e.n_cap + i_self]; nx.idx = e.idx_x[(size_t)b * e.n_cap + i_self]; }
         else {
-            nx = nn_row_fold(rowpart, e.n_cap, gm.T, i_self);
+            nx = nn_row_fold(rowpart, e.n_cap, gm.T, i_self, rows_cstep);
             e.d2x[(size_t)b * e.n_cap + i_self] = nx.d2;             // kept for inspection; nothing on the path reads them
             e.idx_x[(size_t)b * e.n_cap + i_self] = nx.idx;
         }
@@ -2526,7 +2534,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         if (nn2_lds_floats(e->n_cap, 8) * 4 <= 160 * 1024) if (int rc = set_smem((const void *)k_eng_nn_mx8, nn2_lds_floats(e->n_cap, 8) * 4)) return rc;
     }
     // the matrix-pipe kernel in its 8-wave shape (512 targets per workgroup) unless gemm_mode bit 128 asks for the 4-wave one (A/B)
-    const bool nn_mx8 = nn && e->nn_mode == 2 && nn2_lds_floats(e->n_cap, 8) * 4 <= 160 * 1024 && !(e->gemm_mode & 128);
+    const bool nn_mx8 = eng_nn_mx8(*e);
     const dim3 blk(256);
     const dim3 g_lvl(e->G, e->B);
     // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
