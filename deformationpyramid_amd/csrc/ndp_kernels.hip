@@ -1220,6 +1220,22 @@ k_eng_fwd(ndp_engine e, int parity) {
     PT_FLUSH(12);
 }
 
+// XCD-aware placement of a (nvb, B) grid whose nvb workgroups per pair share that pair's data: hardware block L = y nvb + x runs on
+// XCD L % 8 (observed dispatch order, MI355X_MICROARCH.md: used for speed only -- any placement computes the same thing), so the
+// workgroups of one pair are taken from blocks that are congruent mod 8: they then share ONE XCD's L2 instead of pulling the pair's
+// targets, indices and partials into eight of them.  (Pairs beyond the last full group of eight keep the plain order.)
+__device__ __forceinline__ void xcd_pair_block(int nvb, int B, int &b, int &vb) {
+    const int L = blockIdx.y * nvb + blockIdx.x, nfull = B & ~7;
+    if (L < nfull * nvb) {
+        const int slot = L >> 3;
+        b = (slot / nvb) * 8 + (L & 7);
+        vb = slot % nvb;
+    } else {
+        const int r = L - nfull * nvb;
+        b = nfull + r / nvb;
+        vb = r % nvb;
+    }
+}
 #include "ndp_fwd_split.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1851,7 +1867,9 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
 extern "C" __global__ void __launch_bounds__(256)
 k_eng_loss(ndp_engine e, int parity) {
     __shared__ LossSmem sm_;
-    eng_loss_body(e, parity, blockIdx.y, blockIdx.x, gridDim.x, threadIdx.x, true, sm_);
+    int b, vb;
+    xcd_pair_block(gridDim.x, gridDim.y, b, vb);
+    eng_loss_body(e, parity, b, vb, gridDim.x, threadIdx.x, true, sm_);
 }
 
 // backward of the live tiles of every pair that takes an Adam step this tick (two launches, see bwd2/bwd1)
