@@ -176,13 +176,30 @@ _SIGS = {
 EXPORTS = ["ndp_version", "ndp_last_error", "ndp_build_id", "ndp_abi_sizes", "ndp_engine_nn_workspace"] + list(_SIGS)
 
 
+_VARIANT = None
+
+
+def use_variant(path):
+    """Measurement tools only (tools/_modes.py): load `path` -- a timing / experiment build of libndp_hip.so -- instead of the
+    product library, before anything else touched it.  Explicit by construction: no environment variable reaches this, the build-id
+    check is the caller's to give up, and `variant()` lets bench.py record (and refuse) it."""
+    global _VARIANT
+    if _LIB is not None:
+        raise NdpError("use_variant() after the library was loaded")
+    _VARIANT = os.path.abspath(path)
+
+
+def variant():
+    return _VARIANT
+
+
 def lib(allow_build=True):
     """Load the native library (building it first if the source is newer and hipcc exists)."""
     global _LIB
     if _LIB is None:
         # The library carries the digest of the sources it was built from (ndp_build_id): an absent or stale library is
         # rebuilt (under a file lock, so N ranks build once), and one that cannot be rebuilt is refused -- never loaded.
-        override = os.environ.get("NDP_HIP_LIB")     # developer override for timing-only experiment builds
+        override = _VARIANT                          # set by use_variant() only: the package reads no environment variable
         if not override:
             have_hipcc = bool(shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"))
             if allow_build and have_hipcc and _stale():

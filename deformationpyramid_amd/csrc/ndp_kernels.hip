@@ -2560,7 +2560,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     const dim3 g_fwd8(engine_g8(e), e->B);
     if (e->gemm_mode < 0 || e->gemm_mode > 511) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1), 64 (the Adam step inside the fused backward)");
     // both backward layers on the splits: ONE launch (k_eng_bwd_f, stage 3; stage 4 launches nothing) unless bit 16 asks for the two round-3 kernels
-    const bool bwd_fused = (e->gemm_mode & 6) == 6 && !(e->gemm_mode & 16);
+    const bool bwd_fused = (e->gemm_mode & 7) == 7 && !(e->gemm_mode & 16);   // (it reads h1 as the SPLIT forward's plane image: without bit 1 the two launches run)
     if (bwd_fused) if (int rc = set_smem((const void *)k_eng_bwd_f, kSmemBwdFBytes)) return rc;
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd18Bytes)) return rc;
@@ -2578,8 +2578,18 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     const bool persistent = !ev && stage_lo == 0 && stage_hi == NDP_TICK_KERNELS - 1 && bwd_fused && (e->gemm_mode & 1) &&
                             (e->gemm_mode & 256) && !(e->gemm_mode & (32 | 64)) && (!nn || e->nn_mode == 1) && e->G == e->n_cap / NDP_TILE &&
                             e->B * e->G <= 256 && n_ticks > 0;
+    // its pair barriers spin: every one of the B x G workgroups has to be RESIDENT (512 threads and ~147 KB of LDS each: one per CU).  The
+    // occupancy query x the device's CU count has to cover the grid, else the per-stage launches below run instead; a second stream
+    // that holds CUs (bench.py's two engines) can still delay residency -- the variant is for an engine that has the device to itself.
+    bool persistent_fits = false;
     if (persistent) {
         if (int rc = set_smem((const void *)k_eng_tick_small, kSmemTickSmallBytes)) return rc;
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_eng_tick_small, 512, kSmemTickSmallBytes) == hipSuccess &&
+            hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            persistent_fits = (long long)per_cu * cus >= (long long)e->B * e->G;
+    }
+    if (persistent && persistent_fits) {
         HIP_TRY(hipMemsetAsync(e->gmax + e->B, 0, sizeof(unsigned) * e->B, s), "pair barrier counters");
         hipLaunchKernelGGL(k_eng_tick_small, dim3(e->G, e->B), dim3(512), kSmemTickSmallBytes, s, *e, tick0, n_ticks);
         HIP_TRY(hipGetLastError(), "persistent tick launch");

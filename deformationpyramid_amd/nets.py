@@ -84,9 +84,9 @@ def _native_rng_ok():
     same generator state afterwards).  If it ever disagrees the torch-call replay is used instead."""
     if not _NATIVE_RNG["checked"]:
         _NATIVE_RNG["checked"] = True
+        saved = torch.get_rng_state()
         try:
             from . import _native as N
-            saved = torch.get_rng_state()
             torch.manual_seed(987654321)
             a = torch.empty(700).uniform_(-1.5, -0.25)
             torch.empty(333).uniform_(0.0, 1.0)
@@ -116,9 +116,10 @@ def _native_rng_ok():
             ok = ok and rc == 0 and torch.equal(hi[:20].long(), w1[:20]) and torch.equal(hi[20:27].long(), w2)
             ok = ok and L.ndp_rng_skip(ctypes.c_void_p(st.data_ptr()), st.numel(), L.ndp_pair_draws(ops0, 0, 41, 7)) == 0 and torch.equal(st, end)
             _NATIVE_RNG["ok"] = bool(ok)
-            torch.set_rng_state(saved)
         except Exception:
             _NATIVE_RNG["ok"] = False
+        finally:
+            torch.set_rng_state(saved)                    # (also when the check itself raised: the caller's generator is not ours to reseed)
     return _NATIVE_RNG["ok"]
 
 

@@ -87,9 +87,10 @@ typedef struct ndp_warp_job {
 int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_stride,
                           const ndp_warp_job *jobs, int n_jobs, void *stream);
 /* The same warp with the engine's split arithmetic (ndp_engine.gemm_mode & 1): 128-wide contractions and layer 0 as two-way fp16
- * splits (x = hi + 2^-11 lo, three partial products) on the fp16 MFMA, fp32 accumulate; 256 points per workgroup carried through
- * all m levels in LDS.  fp32-level accuracy (within 1e-5 of ndp_pyramid_fwd_batch on warped coordinates), not bitwise the fma
- * chain; operands beyond +-65504 saturate.                                                                                       */
+ * splits in the one-accumulator form (2^6 x = hi + lo, three partial products into one fp32 accumulator) on the fp16 MFMA; 256 points
+ * per workgroup carried through all m levels in LDS.  fp32-level accuracy (within 1e-5 of ndp_pyramid_fwd_batch on warped
+ * coordinates), not bitwise the fma chain; the 2^6 pre-scale means an activation or weight beyond about 1023 (65504 / 64)
+ * saturates (layer 0's pre-activation at 65504).                                                                                  */
 int ndp_pyramid_fwd_batch_split(const ndp_layer_desc *desc, int m, int k0, int p_stride,
                                 const ndp_warp_job *jobs, int n_jobs, void *stream);
 

@@ -568,7 +568,8 @@ def _register_traced(reg_mod, EasyDict, cfg, src, tgt, landmarks=None, seed=0):
             return v
         reg_mod.torch.mean = mean
     try:
-        torch.manual_seed(seed)
+        if seed is not None:                                   # (None: the generator runs on from wherever the caller's sequence left it)
+            torch.manual_seed(seed)
         model = reg_mod.Registration(cfg)
         model.load_pcds(src.numpy(), tgt.numpy(), landmarks=landmarks)
         warped, _, _ = model.register()
@@ -660,6 +661,32 @@ def F10b_surface_benchmark(reg_mod, loss_mod, EasyDict, bench_pairs=8, **_):
          centroid_rows=np.array(cent_rows, dtype=np.float64),
          gen_src_head=first[0][:16].numpy(), gen_tgt_head=first[1][:16].numpy(), gen_flow_head=first[2][:16].numpy(),
          gen_counts=np.array([first[0].shape[0], first[1].shape[0], int(first[3].sum())]))
+
+
+def F10c_surface_benchmark_seeds(reg_mod, loss_mod, EasyDict, bench_pairs=8, **_):
+    """The reference's own SEED-TO-SEED distribution on the F10b surface pairs: eval_nolearned.py:22 seeds the process ONCE and then
+    registers pair after pair, so one "run" here is torch.manual_seed(s) followed by the eight pairs in order, s = 0..7 -- 64 metric
+    rows.  (F10b holds one draw per pair, seeded per pair: whether a +6 % EPE of another arithmetic is noise or bias cannot be told
+    from a single draw.)  The GPU path's runs are seeded the same way (tests/test_registration_gpu.py, bench.py)."""
+    n_seeds = 8
+    all_rows, all_iters, keys = [], [], None
+    for s in range(n_seeds):
+        torch.manual_seed(s)
+        rs, its = [], []
+        for p in range(bench_pairs):
+            src, tgt, flow_gt, overlap = surface_pair(p)
+            cfg = ndp_config(EasyDict)
+            warped, trace = _register_traced(reg_mod, EasyDict, cfg, src, tgt, seed=None)
+            m = loss_mod.compute_flow_metrics(warped - src, flow_gt, overlap)
+            keys = list(m.keys())
+            rs.append(list(m.values()))
+            its.append(sum(len(t) for t in trace))
+        all_rows.append(rs); all_iters.append(its)
+        a = np.array(rs)
+        print(f"seed {s}: full-epe {a[:, keys.index('full-epe')].mean():.3f} AccS {a[:, keys.index('full-AccS')].mean():.2f} "
+              f"AccR {a[:, keys.index('full-AccR')].mean():.2f}  iters {np.mean(its):.1f}", flush=True)
+    save("F10c_surface_benchmark_seeds", keys=np.array(keys), rows=np.array(all_rows, dtype=np.float64), iters=np.array(all_iters),
+         seeds=np.arange(n_seeds), pairs=np.arange(bench_pairs))
 
 
 def F12_nsfp(nets, loss_mod, reg_mod, EasyDict, **_):
@@ -949,7 +976,7 @@ def main():
         "F1": F1_init, "F2": F2_layer_forward, "F3": F3_chamfer, "F4": F4_F5_iteration,
         "F7": F7_end_to_end, "F8": F8_metrics, "F9": F9_landmarks, "F9b": F9b_lndp_end_to_end,
         "F9c": F9c_mixed_landmark_chamfer,
-        "F10": F10_benchmark, "F10b": F10b_surface_benchmark, "F11": F11_nonrigidity, "F12": F12_nsfp,
+        "F10": F10_benchmark, "F10b": F10b_surface_benchmark, "F10c": F10c_surface_benchmark_seeds, "F11": F11_nonrigidity, "F12": F12_nsfp,
         "F13": F13_shape_transfer, "F14": F14_nerfies, "F15": F15_embedded_deformation,
     }
     only = [s for s in args.only.split(",") if s]

@@ -685,10 +685,11 @@ def test_onepass_nn_is_exact_on_adversarial_layouts(dev, name, matrix):
 
 @pytest.mark.parametrize("arith,nn_mode,G", [("bitwise", 0, 4), ("bitwise", 1, 4), ("bitwise", 2, 4),
                                              ("split", 2, 2), ("split", 0, 2), ("split", 1, 2)])
-def test_engine_matches_oracle_at_the_bench_geometry(dev, arith, nn_mode, G):
-    """What bench.py times: S = T = 2000 samples, 8 resident pairs of slightly different sizes, 3 iterations x 2 levels, G
-    workgroups per pair as the bench's 128-slot engines get them (4 four-wave workgroups with the fp32-MFMA level kernels,
-    2 eight-wave workgroups with the split ones) -- with each nearest-neighbour kernel (0 one-pass on the vector pipe, 1
+def test_engine_matches_oracle_at_the_bench_cloud_sizes(dev, arith, nn_mode, G):
+    """The bench's cloud sizes in a SMALL engine: S = T = 2000 samples, 8 resident pairs of slightly different sizes, 3 iterations x
+    2 levels, G workgroups per pair as a 128-slot engine gets them (4 four-wave workgroups with the fp32-MFMA level kernels,
+    2 eight-wave workgroups with the split ones; the slot geometry bench.py runs since round 4 -- 256 slots, G = 1 -- is the next
+    test's) -- with each nearest-neighbour kernel (0 one-pass on the vector pipe, 1
     latency shape, 2 one-pass on the matrix pipe): identical step counts, loss and warped samples within the per-step budget."""
     eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=2000, T=2000, m=2, iters=3, early_stop=False,
                                           w_cd=1.0, trunc=1e9, B=8, G=G, nn_mode=nn_mode, arith=arith)
@@ -697,6 +698,53 @@ def test_engine_matches_oracle_at_the_bench_geometry(dev, arith, nn_mode, G):
         assert st.level == 2 and st.total_steps == 6
         assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
         assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+
+
+def test_engine_matches_oracle_at_the_slot_geometry_bench_runs(dev, arith):
+    """The engine exactly as bench.py builds it since round 4: B = 256 resident slots per engine, hence G = 1 (ONE level-kernel
+    workgroup per pair, 32 tiles per gradient accumulator) on the split path (G = 2 four-wave workgroups on the bitwise one), the
+    512-target matrix-pipe nearest-neighbour kernel with its every-second-slot row partials, and the XCD-aware block -> pair
+    placement of the loss and nearest-neighbour stages.  S = T = 2000; eight distinct pairs of slightly different sizes, each
+    replicated 32 times across the slots (slot s holds pair s % 8): slots 0..7 against the oracle at the usual budget, and every
+    replica BIT-identical to its original -- a slot's result must not depend on which workgroup / XCD served it."""
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    B, NP, S, T, m, iters = 256, 8, 2000, 2000, 2, 3
+    cfg = OptConfig(m=m, iters=iters, early_stop=False, w_cd=1.0, trunc=1e9)
+    eng, refs, loads = None, [], []
+    for b in range(NP):
+        pyr = seeded_pyramid(7 + b, m=m, **VARIANTS["se3aa"])
+        d = pyr.descs[0]
+        if eng is None:
+            eng = BatchedEngine(d, cfg, B, n_cap=S, t_cap=T, device=dev, **engine_modes(arith, S))
+        Sb, Tb = S - 7 * b, T - 3 * b
+        src = cloud(Sb, 100 + b)
+        c, s_ = np.cos(0.2), np.sin(0.2)
+        Rz = torch.tensor([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+        tgt = (cloud(Tb, 200 + b) @ Rz.T + torch.tensor([0.03, -0.02, 0.01])).contiguous()
+        loads.append((src, Sb, tgt, pyr.store))
+        params_all = np.concatenate([pyr.store[i, :d.param_count].numpy() for i in range(m)])
+        refs.append(O().optimize([cdesc(d)] * m, params_all, src.numpy(), 0, Sb, None, tgt.numpy(), k0=K0, iters=iters,
+                                 w_cd=1.0, trunc=1e9, early_stop=False, nthreads=4, ratio=0.001))
+    for slot in range(B):
+        src, Sb, tgt, store = loads[slot % NP]
+        eng.load(slot, src, 0, Sb, None, tgt, store)
+    if arith == "split":
+        assert eng.G == 1 and eng.c_engine.gemm_mode == 7 and eng.c_engine.nn_mode == 2
+    else:
+        assert eng.G == 2 and eng.c_engine.gemm_mode == 0
+    states = eng.run_until_done(chunk=8)
+    for b in range(NP):
+        st, ref = states[b], refs[b]
+        assert st.level == 2 and st.total_steps == 6
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+        assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+    P = eng.P
+    for slot in range(NP, B):
+        o = slot % NP
+        assert states[slot].loss == states[o].loss and states[slot].total_steps == states[o].total_steps, slot
+        assert torch.equal(eng.params[slot, :, :P], eng.params[o, :, :P]), slot
+        assert torch.equal(eng.final_points(slot, states[slot]), eng.final_points(o, states[o])), slot
+        assert torch.equal(eng.d2y[slot], eng.d2y[o]) and torch.equal(eng.idx_y[slot], eng.idx_y[o]), slot
 
 
 def test_engine_nn_shapes_are_bit_identical(dev):
@@ -711,7 +759,7 @@ def test_engine_nn_shapes_are_bit_identical(dev):
         assert torch.equal(runs[0][0], other[0]) and torch.equal(runs[0][2], other[2]) and torch.equal(runs[0][3], other[3])
 
 
-@pytest.mark.parametrize("gemm_mode", [1, 2, 4, 7])
+@pytest.mark.parametrize("gemm_mode", [1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize("tag", ["se3aa", "sim3eu", "sflow"])
 def test_engine_on_fp16_splits_stays_inside_the_parity_budget(dev, tag, gemm_mode):
     """Opt-in gemm_mode mask (1 forward, 2 bwd1, 4 bwd2: their 128x128 contractions from two-way fp16 splits on the fp16 MFMA): the

@@ -49,7 +49,7 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
     # gemm_mode 7: the split forward does not store h0 (bwd1 recomputes it); bit 8 makes it store h0 for the comparisons below --
     # test_h0_is_recomputed... pins that the bit changes nothing else
     # + 32: the fused backward (one launch for both layers, dz1 in LDS) also writes dz1 to HBM, where the two-launch form leaves it
-    mode = gemm_mode if (gemm_mode & 6) != 6 else (gemm_mode | (0 if gemm_mode & 16 else 32) | (8 if keep_h0 else 0))
+    mode = gemm_mode if (gemm_mode & 7) != 7 else (gemm_mode | (0 if gemm_mode & 16 else 32) | (8 if keep_h0 else 0))
     eng = BatchedEngine(d, cfg, 1, n_cap=S, t_cap=T, device=dev, gemm_mode=mode, nn_mode=1, G=G)
     g = torch.Generator().manual_seed(3)
     src = (torch.rand(S, 3, generator=g) - 0.5).contiguous()
@@ -65,7 +65,7 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
     eng.run_stages(0, 2)                                      # forward, nearest neighbours, loss / dL/dx'
     torch.cuda.synchronize()
     out["act_fwd"] = eng.act[0].cpu().clone()                 # h0, h1, h2
-    if (mode & 6) == 6 and not mode & 16:                     # the fused backward reads h1 as the forward's plane image, not as fp32 rows
+    if (mode & 7) == 7 and not mode & 16:                     # the fused backward reads h1 as the forward's plane image, not as fp32 rows
         out["act_fwd"][1] = _decode_h1_image(out["act_fwd"][1])
     out["heads"] = eng.heads[0].cpu().clone()
     out["dO"] = eng.dO[0].cpu().clone()
@@ -156,7 +156,7 @@ def _errors(r):
     return out
 
 
-@pytest.mark.parametrize("G", [None, 2])
+@pytest.mark.parametrize("G", [None, 2, 1])
 @pytest.mark.parametrize("tag,level", [("se3aa", 0), ("se3aa", 3), ("sim3eu", 1), ("sflow", 2)])
 def test_split_kernels_are_as_close_to_float64_as_the_fp32_chain(dev, tag, level, G):
     """Bar, per output tensor of every kernel, split path vs fp32 chain, both against float64:
@@ -171,7 +171,8 @@ def test_split_kernels_are_as_close_to_float64_as_the_fp32_chain(dev, tag, level
         with the bench's 16 tiles per accumulator (G = 2) the same tensors are at 0.5-0.75x.
     Everything stays below 5e-6 of its tensor's scale in absolute terms (the north-star budget is 1e-4 on warped coordinates).
     The per-tensor numbers of every case are written to gpurun_out/split_accuracy_*.json (kept under profiles/).
-    G: workgroups per pair -- None: one per tile (the latency shape), 2: the bench's throughput shape (16 tiles per accumulator;
+    G: workgroups per pair -- None: one per tile (the latency shape), 2: a 128-slot engine's shape (16 tiles per accumulator), 1: the shape
+    bench.py runs since round 4 (256 slots per engine: ONE workgroup and one accumulator per pair, 32 tiles;
     the same G for both arithmetics, so that the comparison is between arithmetics, not between partial counts)."""
     import json
     import os

@@ -2,6 +2,10 @@
 keyword arguments.  (The package itself reads no environment variable: modes are constructor arguments.)"""
 import os
 
+if os.environ.get("NDP_HIP_LIB"):                    # an experiment build (tools/experiments/build_variant.sh) under a TOOL -- never under the
+    from deformationpyramid_amd import _native as _N     # product or bench.py, which do not import this module
+    _N.use_variant(os.environ["NDP_HIP_LIB"])
+
 
 def from_env():
     kw = {}

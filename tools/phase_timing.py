@@ -96,7 +96,7 @@ if eng.nn_mode == 2:
     print(f"nn_mx{'8' if mx8 else ''}: {tot / wgs:.0f} cycles per workgroup (all sources x {512 if mx8 else 256} targets; thread 0 wall)")
     for i, nm in enumerate(nmn):
         print(f"   {nm:58s} {buf[64 + i] / wgs:9.0f}  {100.0 * buf[64 + i] / max(tot, 1):5.1f} %")
-FUSED = (eng.gemm_mode & 6) == 6 and not (eng.gemm_mode & 16)
+FUSED = (eng.gemm_mode & 7) == 7 and not (eng.gemm_mode & 16)
 if FUSED:
     # default: three stamps per tile, one after each barrier (any stamp INSIDE a barrier interval pins the schedule of this
     # register-capped kernel and its timing build spills); -DNDP_PHASE_TIMING_FINE adds the inner ones (distorted: read with care)
