@@ -14,7 +14,10 @@ extra = sys.argv[3:]
 lib = os.path.join(ROOT, "gpurun_out", "libndp_phase.so")
 os.makedirs(os.path.dirname(lib), exist_ok=True)
 src = os.path.join(ROOT, "deformationpyramid_amd", "csrc", "ndp_kernels.hip")
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+if os.environ.get("NDP_PT_LIB"):          # a timing build made elsewhere (e.g. of another revision of the sources): use it as it is
+    lib = os.path.abspath(os.environ["NDP_PT_LIB"])
+else:
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
                        "-DNDP_PHASE_TIMING"] + extra + ["-o", lib, src])
 os.environ["NDP_HIP_LIB"] = lib
 import torch
