@@ -21,7 +21,7 @@ preps = []
 for i in range(B):
     s, t, _, _ = synthetic_pair(i)
     preps.append(model._prepare(s.to(dev), t.to(dev), None))
-eng = model._engine(B, preps[0])
+eng = model._engine(B, preps[0], n_hint=int(os.environ.get('NDP_TICK_NHINT', '0')))      # (NDP_TICK_NHINT: a larger point capacity -> other strides between the pairs' buffers)
 for b, p in enumerate(preps):
     eng.load_jobs([p.load_job(b)])
 eng.run_ticks(4)
