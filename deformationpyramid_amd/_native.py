@@ -71,7 +71,8 @@ class LoadJob(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("tgt", ctypes.c_void_p), ("perm_s", ctypes.c_void_p),
                 ("perm_t", ctypes.c_void_p), ("ldmk_s", ctypes.c_void_p), ("ldmk_t", ctypes.c_void_p),
                 ("params", ctypes.c_void_p), ("means", ctypes.c_void_p),
-                ("slot", ctypes.c_int), ("K", ctypes.c_int), ("S", ctypes.c_int), ("T", ctypes.c_int)]
+                ("slot", ctypes.c_int), ("K", ctypes.c_int), ("S", ctypes.c_int), ("T", ctypes.c_int),
+                ("n_src", ctypes.c_int), ("n_tgt", ctypes.c_int)]
 
 
 MAX_WARP_JOBS = 32

@@ -2122,6 +2122,36 @@ k_pair_means(const float *src, int n_src, const float *tgt, int n_tgt, float *me
 struct LoadJobs {
     ndp_load_job j[NDP_MAX_LOAD_JOBS];
 };
+// the means of the raw clouds of the jobs that ask for them (n_src > 0), ONE launch per load call instead of one k_pair_means per pair
+// (24 576 launches per bench run, 4.6 % of the kernel time under two engines' contention: profiles/r04_bench_kernel_stats.csv):
+// blockIdx.y = job, blockIdx.x = 0 source / 1 target; per block the code of k_pair_means -- same order, same bits
+extern "C" __global__ void __launch_bounds__(1024)
+k_pair_means_jobs(LoadJobs jobs) {
+    __shared__ double red[3][1024];
+    const ndp_load_job jb = jobs.j[blockIdx.y];
+    if (!jb.params || !jb.means || jb.n_src <= 0) return;
+    const float *x = blockIdx.x ? jb.tgt : jb.src;
+    const int n = blockIdx.x ? jb.n_tgt : jb.n_src, t = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int p0 = t; p0 < n; p0 += 4 * 1024) {
+        float v[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int p = p0 + 1024 * u;
+            v[u][0] = v[u][1] = v[u][2] = 0.f;
+            if (p < n) { v[u][0] = x[3 * (size_t)p]; v[u][1] = x[3 * (size_t)p + 1]; v[u][2] = x[3 * (size_t)p + 2]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s0 += (double)v[u][0]; s1 += (double)v[u][1]; s2 += (double)v[u][2]; }
+    }
+    red[0][t] = s0; red[1][t] = s1; red[2][t] = s2;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1) {
+        if (t < d) { red[0][t] += red[0][t + d]; red[1][t] += red[1][t + d]; red[2][t] += red[2][t + d]; }
+        __syncthreads();
+    }
+    if (t < 4) jb.means[4 * blockIdx.x + t] = t < 3 ? (float)(red[t][0] / (double)n) : 0.f;
+}
 extern "C" __global__ void __launch_bounds__(256)
 k_eng_load(ndp_engine e, int parity, LoadJobs jobs) {
     const ndp_load_job jb = jobs.j[blockIdx.y];
@@ -2407,6 +2437,7 @@ extern "C" int ndp_engine_load(const ndp_engine *e, int tick, const ndp_load_job
     if (n_jobs == 0) return 0;
     LoadJobs lj;
     memset(&lj, 0, sizeof lj);
+    bool any_means = false;
     for (int j = 0; j < n_jobs; ++j) {
         const ndp_load_job &q = jobs[j];
         if (q.slot < 0 || q.slot >= e->B) return fail(NDP_E_INVALID, "ndp_engine_load: slot out of range");
@@ -2418,8 +2449,13 @@ extern "C" int ndp_engine_load(const ndp_engine *e, int tick, const ndp_load_job
                 return fail(NDP_E_INVALID, "ndp_engine_load: null cloud pointer");
             if (!aligned16(q.params)) return fail(NDP_E_INVALID, "ndp_engine_load: params must be 16-byte aligned");
         }
+        if (q.params && q.n_src > 0) {
+            if (!q.means || !q.src || !q.tgt || q.n_tgt < 1) return fail(NDP_E_INVALID, "ndp_engine_load: means to compute need src, tgt, n_tgt and the means buffer");
+            any_means = true;
+        }
         lj.j[j] = q;
     }
+    if (any_means) hipLaunchKernelGGL(k_pair_means_jobs, dim3(2, n_jobs), dim3(1024), 0, (hipStream_t)stream, lj);
     hipLaunchKernelGGL(k_eng_load, dim3(32, n_jobs), dim3(256), 0, (hipStream_t)stream, *e, tick & 1, lj);
     HIP_TRY(hipGetLastError(), "k_eng_load launch");
     return 0;

@@ -174,7 +174,8 @@ class BatchedEngine:
         """Fill / park slots, one launch per 16 jobs (ndp_engine_load).  Each job is a dict with `slot` and either
         nothing else (park) or: params [m,p_stride] device tensor, K, S, T, src [*,3], tgt [*,3] | None,
         perm_s / perm_t (device int32, first S / T entries used) | None, ldmk_s / ldmk_t [K,3] | None,
-        means [8] | None.  The tensors must stay alive until the launch has run (the caller holds them)."""
+        means [8] | None (with n_src / n_tgt > 0 the load call computes them into that tensor first: one launch for the group).
+        The tensors must stay alive until the launch has run (the caller holds them)."""
         ptr = lambda t: t.data_ptr() if t is not None else None
         for i0 in range(0, len(jobs), N.MAX_LOAD_JOBS):
             group = jobs[i0:i0 + N.MAX_LOAD_JOBS]
@@ -195,6 +196,7 @@ class BatchedEngine:
                 q.perm_s, q.perm_t = ptr(j.get("perm_s")), ptr(j.get("perm_t"))
                 q.ldmk_s, q.ldmk_t = ptr(j.get("ldmk_s")), ptr(j.get("ldmk_t"))
                 q.means = ptr(j.get("means"))
+                q.n_src, q.n_tgt = int(j.get("n_src", 0)), int(j.get("n_tgt", 0))     # > 0: the means are computed by this call
                 self._geom_h[q.slot] = (K, S, T, 0)
             N.check(self.lib.ndp_engine_load(ctypes.byref(self.c_engine), self.tick, arr, len(group),
                                              N.stream_ptr(self.device)), "ndp_engine_load")

@@ -34,14 +34,15 @@ class _Prepared:
     """Everything one pair needs on the device before it enters an engine slot: the raw clouds, their means, the
     freshly initialised pyramid and the sampling permutations (one pinned upload), optional landmarks."""
     __slots__ = ("src_pcd", "tgt_pcd", "means", "buf", "store", "perm_s", "perm_t", "K", "S", "T", "ldmk_s", "ldmk_t",
-                 "desc", "result", "state")
+                 "desc", "result", "state", "index")
 
     def tensors(self):
         return [t for t in (self.src_pcd, self.tgt_pcd, self.means, self.buf, self.ldmk_s, self.ldmk_t) if t is not None]
 
     def load_job(self, slot):
         return dict(slot=slot, params=self.store, K=self.K, S=self.S, T=self.T, src=self.src_pcd, tgt=self.tgt_pcd,
-                    perm_s=self.perm_s, perm_t=self.perm_t, ldmk_s=self.ldmk_s, ldmk_t=self.ldmk_t, means=self.means)
+                    perm_s=self.perm_s, perm_t=self.perm_t, ldmk_s=self.ldmk_s, ldmk_t=self.ldmk_t, means=self.means,
+                    n_src=self.src_pcd.shape[0], n_tgt=self.tgt_pcd.shape[0])     # (the means are computed by the load call)
 
     def warp_job(self, store):
         return (store, self.src_pcd, self.means, self.means[4:])
@@ -85,13 +86,14 @@ class _PinRing:
 
 class _BatchCtx:
     """What the lanes of one register_batch call share."""
-    __slots__ = ("reg", "preps", "next_prepared", "fin_stream", "main", "chunk", "m", "exhausted", "handed_out", "total_slots")
+    __slots__ = ("reg", "preps", "next_prepared", "fin_stream", "main", "chunk", "m", "exhausted", "handed_out", "total_slots", "sink")
 
     def __init__(self, reg, preps, next_prepared, fin_stream, main, chunk, m):
         self.reg, self.preps, self.next_prepared = reg, preps, next_prepared
         self.fin_stream, self.main, self.chunk, self.m = fin_stream, main, chunk, m
         self.exhausted = False
         self.handed_out, self.total_slots = 0, 0          # pairs given to lanes so far / slots of all lanes (set once they exist)
+        self.sink = None
 
 
 
@@ -173,6 +175,10 @@ class _Lane:
                     out.record_stream(ctx.main)
                     p.result = out
                     p.release()
+                if ctx.sink is not None:
+                    for slot, p in done:
+                        ctx.sink(p.index, p.result, p.state)
+                        p.result = None
         self.pending = handle
 
 
@@ -258,7 +264,7 @@ class Registration:
                 timer.tictoc(key, total / calls)
 
     # ------------------------------------------------------------------ batched extension
-    def register_batch(self, pairs, slots=64, chunk=8, prefetch=True, engines=1, workers=3):
+    def register_batch(self, pairs, slots=64, chunk=8, prefetch=True, engines=1, workers=3, sink=None):
         """pairs: sequence of (src, tgt) or (src, tgt, (ldmk_s, ldmk_t)).  Pairs are prepared in order
         (so the CPU RNG stream is consumed exactly as by sequential register() calls) and optimised
         `slots` at a time per engine, finished slots being refilled.  With prefetch=True the host-side preparation
@@ -266,7 +272,9 @@ class Registration:
         one generator-stepping thread (see below: bit-identical to the sequential order whatever the thread count).
         engines > 1 keeps that many independent engines ticking on their own HIP streams: their launches interleave on
         the GPU, so the VALU-bound and latency-bound kernels of one overlap the MFMA-bound kernels of another.
-        Returns [(warped, iter_cnt)] in input order."""
+        Returns [(warped, iter_cnt)] in input order.
+        sink(i, warped, state): called (on the calling thread, in completion order) for every finished pair INSTEAD of keeping its
+        result -- a long stream of pairs then holds no more than the resident ones; the call returns None."""
         pairs = list(pairs)
         if not pairs:
             return []
@@ -408,11 +416,13 @@ class Registration:
                 t.record_stream(stream)
                 t.record_stream(fin_stream)
             preps[i] = p
+            p.index = i
             return i, p
 
         m = self.config.m
         main = torch.cuda.current_stream(dev)
         ctx = _BatchCtx(self, preps, next_prepared, fin_stream, main, chunk, m)
+        ctx.sink = sink
 
         # the cyclic collector's FULL passes over thousands of live pair objects stalled every lane for 50-85 ms a few times per
         # batch (rocprofv3 trace of the bench); nothing in the loop builds reference cycles worth collecting before it ends.  Only
@@ -466,7 +476,7 @@ class Registration:
             main.wait_stream(lane.stream)
         main.wait_stream(fin_stream)
         self.last_states = [p.state for p in preps]
-        results = [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
+        results = None if sink is not None else [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
         ctx.preps = ctx.next_prepared = None                     # nothing of this call stays reachable but the results
         return results
 
@@ -590,7 +600,8 @@ class Registration:
         p.store = p.buf[:n_par].view(c.m, stride)
         di = p.buf[n_par:].view(torch.int32)
         p.perm_s, p.perm_t = di[:ns], di[samples:samples + nt]
-        p.means = ops.pair_means(src_pcd, tgt_pcd)                                # :150-153
+        p.means = torch.empty(8, device=dev, dtype=torch.float32)                 # :150-153: filled by the slot's load call (ONE launch per
+                                                                                   # group of up to 16 pairs instead of one per pair)
         p.ldmk_s = p.ldmk_t = None
         if landmarks is not None:
             p.ldmk_s = landmarks[0].to(dev).float().contiguous()                  # :162-164 (centred on the device)

@@ -293,15 +293,19 @@ int ndp_engine_run(const ndp_engine *e, int tick0, int n_ticks, void *stream);
  *   pts[slot][0][i]   = i < K ? ldmk_s[i] - mean_s : src[perm_s[i-K]] - mean_s      (i < K+S, rest zero)
  *   ldmk_t[slot][k]   = ldmk_t[k] - mean_t ;  tgt[slot][j] = tgt[perm_t[j]] - mean_t  (j < T)
  *   params[slot]      = params ; adam_m = adam_v = 0 ; geom = (K,S,T) ; state[tick & 1][slot] = fresh
- * perm_* NULL = identity, means NULL = no centring.  A job with params == NULL parks the slot (level = m).
+ * perm_* NULL = identity, means NULL = no centring (n_src > 0: the means are computed by this call, see the struct).  A job with
+ * params == NULL parks the slot (level = m).
  * `jobs` is a HOST array (copied into the kernel arguments); at most NDP_MAX_LOAD_JOBS per call.       */
 typedef struct ndp_load_job {
     const float *src, *tgt;          /* raw clouds [n][3] (device) */
     const int *perm_s, *perm_t;      /* first S / T entries of the sampling permutations (device int32) or NULL */
     const float *ldmk_s, *ldmk_t;    /* [K][3] or NULL */
     const float *params;             /* [m][p_stride] initial parameters (device) or NULL = park */
-    const float *means;              /* [8] from ndp_pair_means, or NULL */
+    float *means;                    /* [8] as ndp_pair_means leaves them, or NULL.  With n_src > 0 they are an OUTPUT first: the call
+                                        computes the means of src [n_src] / tgt [n_tgt] into `means` -- ONE launch for all such jobs
+                                        of the call, the arithmetic of ndp_pair_means (same bits) -- and then centres with them */
     int slot, K, S, T;
+    int n_src, n_tgt;                /* points of the raw clouds when the means are to be computed here, else 0 */
 } ndp_load_job;
 #define NDP_MAX_LOAD_JOBS 16
 int ndp_engine_load(const ndp_engine *e, int tick, const ndp_load_job *jobs, int n_jobs, void *stream);

@@ -35,7 +35,7 @@ def test_struct_layouts_match_the_header():
     assert ctypes.sizeof(_native.PairGeom) == 16
     assert _native.Engine.break_threshold_ratio.offset % 8 == 0
     assert _native.Engine.geom.offset % 8 == 0
-    assert ctypes.sizeof(_native.WarpJob) == 48 and ctypes.sizeof(_native.LoadJob) == 80     # 5 / 8 pointers + 2 / 4 ints
+    assert ctypes.sizeof(_native.WarpJob) == 48 and ctypes.sizeof(_native.LoadJob) == 88     # 5 / 8 pointers + 2 / 6 ints
     header = open(os.path.join(ROOT, "include", "ndp_hip.h")).read()
     assert int(re.search(r"#define NDP_MAX_WARP_JOBS (\d+)", header).group(1)) == _native.MAX_WARP_JOBS
     assert int(re.search(r"#define NDP_MAX_LOAD_JOBS (\d+)", header).group(1)) == _native.MAX_LOAD_JOBS

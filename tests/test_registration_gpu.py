@@ -147,6 +147,64 @@ def test_register_reproduces_reference_metrics_on_surface_pairs(cfg, golden, ari
     assert not within(g["zero_flow_rows"]) and not within(g["centroid_rows"])
 
 
+def test_register_batch_sink_receives_what_the_call_would_return(cfg, arith):
+    """register_batch(..., sink=f): every finished pair is handed to f (index, warped points, final state) instead of being kept --
+    the same tensors, bit for bit, as the list the call returns without a sink (bench.py streams its steps through one call)."""
+    from deformationpyramid_amd.config import Config
+    from deformationpyramid_amd.registration import Registration
+    from deformationpyramid_amd.synthetic import synthetic_pair
+    c = Config(cfg, samples=300, m=3, iters=30)
+    pairs = [synthetic_pair(40 + p, n_total=1400 + 64 * p)[:2] for p in range(7)]
+    model = Registration(c, **registration_modes(arith))
+    torch.manual_seed(5)
+    ref = model.register_batch(pairs, slots=3, engines=2)
+    steps = [s.total_steps for s in model.last_states]
+    got = {}
+    torch.manual_seed(5)
+    assert model.register_batch(pairs, slots=3, engines=2, sink=lambda i, w, st: got.__setitem__(i, (w.clone(), st.total_steps))) is None
+    assert sorted(got) == list(range(len(pairs)))
+    for i, (w, _) in enumerate(ref):
+        assert torch.equal(w, got[i][0]) and got[i][1] == steps[i]
+
+
+def test_surface_pair_metrics_sit_inside_the_references_seed_to_seed_distribution(cfg, golden, arith):
+    """F10c: the reference's OWN distribution over process seeds on the eight surface pairs (eval_nolearned.py:22 seeds once, then
+    registers pair after pair: 8 seeds x 8 pairs, seed means of full-EPE 6.06 .. 6.93 -- F10b's single draw per pair, 6.12, is a lucky
+    one).  The GPU path under the same eight seeds (torch.manual_seed(s), then the pairs in order: register_batch draws the pyramid
+    initialisations and the sampling permutations in the order sequential register() calls do): its mean over the 64 runs of
+    full-EPE / AccS / AccR within two standard errors of the difference of the two 8-seed means; the mean number of loss
+    evaluations per pair likewise (or within 5 %).  A bias of the arithmetic (fp16 range clamp, an early-stop difference) would show here; trajectory
+    noise does not."""
+    from deformationpyramid_amd.loss import compute_flow_metrics
+    from deformationpyramid_amd.registration import Registration
+    from deformationpyramid_amd.synthetic import surface_pair
+    g = golden("F10c_surface_benchmark_seeds")
+    keys = list(g["keys"])
+    ref = g["rows"]                                                    # [seed][pair][metric]
+    dev = torch.device("cuda", 0)
+    sp = [surface_pair(int(p)) for p in g["pairs"]]
+    dp = [(a.to(dev), b.to(dev)) for a, b, _, _ in sp]
+    model = Registration(cfg, **registration_modes(arith))
+    rows, iters = [], []
+    for seed in g["seeds"]:
+        torch.manual_seed(int(seed))
+        res = model.register_batch(dp, slots=len(dp), engines=1)
+        iters.append(np.mean([s.total_evals for s in model.last_states]))      # loss evaluations: what the fixture's traces count
+        rows.append([[compute_flow_metrics(w - a.to(dev), fg.to(dev), ov.to(dev))[k] for k in keys] for (w, _), (a, _, fg, ov) in zip(res, sp)])
+    rows = np.array(rows)
+    report = {}
+    for k in ("full-epe", "full-AccS", "full-AccR"):
+        j = keys.index(k)
+        ref_seed, got_seed = ref[:, :, j].mean(1), rows[:, :, j].mean(1)
+        se = np.sqrt(ref_seed.var(ddof=1) / len(ref_seed) + got_seed.var(ddof=1) / len(got_seed))
+        report[k] = (float(got_seed.mean()), float(ref_seed.mean()), float(se))
+    for k, (got, want, se) in report.items():
+        assert abs(got - want) < 2.0 * se, report
+    ref_it = g["iters"].mean(1)                                        # per seed: mean loss evaluations per pair (282 .. 666 from pair to pair)
+    se_it = np.sqrt(ref_it.var(ddof=1) / len(ref_it) + np.var(iters, ddof=1) / len(iters))
+    assert abs(np.mean(iters) - ref_it.mean()) < max(2.0 * se_it, 0.05 * ref_it.mean()), (np.mean(iters), ref_it.mean(), se_it)
+
+
 def test_register_batch_equals_sequential_register(cfg, arith):
     """Same seed, same pairs: the batched path consumes the CPU RNG in the same order as sequential
     register() calls and lands on the same answer up to trajectory noise; with prefetch on or off the
