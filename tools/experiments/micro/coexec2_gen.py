@@ -43,6 +43,11 @@ def filler(kind, n):
                 f"v_cvt_f32_f16 {fd(n)}, {fs(n)}",
                 f"v_sub_f32 {fd(n)}, {fs(n)}, {fs(n + 1)}",
                 f"v_cvt_pk_f16_f32 {fd(n)}, {fs(n + 2)}, {fs(n + 3)}"][n % 5]
+    if kind == "fmix":  # the split by v_fma_mix: hi half, hi half, lo half (reads the hi pair), lo half
+        return [f"v_fma_mixlo_f16 {fd(n)}, {fs(n)}, {fs(n + 1)}, 0",
+                f"v_fma_mixhi_f16 {fd(n)}, {fs(n + 2)}, {fs(n + 1)}, 0",
+                f"v_fma_mixlo_f16 {fd(n)}, {fs(n)}, {fs(n + 1)}, -{fs(n + 3)} op_sel_hi:[0,0,1]",
+                f"v_fma_mixhi_f16 {fd(n)}, {fs(n + 2)}, {fs(n + 1)}, -{fs(n + 3)} op_sel:[0,0,1] op_sel_hi:[0,0,1]"][n % 4]
     if kind == "lds":
         return f"ds_read_b128 {ld(n)}, {LDSA} offset:{(n % 8) * 1024}"
     if kind == "mixl":  # four of the split's instructions, then one LDS read
@@ -159,7 +164,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("# cfg shape kind k | cycles per MFMA (mean / min / max over MFMA waves) | fillers per MFMA issued by the partner (cross only) | wall us | MFMA-wave GHz\n");
     for (const Var &v : vars) {
-        if (only && !strstr(v.cfg, only)) continue;
+        if (only && !strstr(v.cfg, only) && !strstr(v.kind, only)) continue;      // argv[1]: a configuration (w1, w2p ..) or a filler kind
         const size_t ldsb = 100 * 1024;                       // more than half a CU's LDS: one workgroup per CU
         hipFuncSetAttribute((const void *)v.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
         hipLaunchKernelGGL(v.fn, dim3(NB), dim3(v.threads), ldsb, 0, cyc, out, nit);
@@ -192,7 +197,7 @@ int main(int argc, char **argv) {
 def main():
     variants = []
     for shape, kmax in (("32", 12), ("16", 6)):
-        for kind in ("med3", "cvt", "sub", "fma", "mix"):
+        for kind in ("med3", "cvt", "sub", "fma", "mix", "fmix"):
             for k in range(0, kmax + 1):
                 if k == 0 and kind != "mix":
                     continue
@@ -202,7 +207,7 @@ def main():
         for k in (5, 10) if shape == "32" else (5,):
             variants.append(("w1", shape, "mixl", k))
         for cfg in ("w2", "w2p"):
-            for kind in ("mix", "fma"):
+            for kind in ("mix", "fma", "fmix"):
                 for k in range(0, kmax + 1, 1 if shape == "16" else 2):
                     if k == 0 and kind != "mix":
                         continue
