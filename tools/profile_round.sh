@@ -31,7 +31,8 @@ python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_bench/*.db | head -1) $O/
 NDP_GEMM_MODE=23 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_tick_2launch -o tick -- python $R/tools/tick_bench.py 128 24 > $O/${TAG}_prof_tick_2launch.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_tick_2launch/*.db | head -1) $O/${TAG}_tick_kernel_stats_2launch.csv > /dev/null
 # what the second and third engine buy
-bash $R/tools/experiments/sweep_engines.sh 2 > $O/${TAG}_engines_sweep.txt 2>&1
+bash $R/tools/experiments/sweep3.sh "2:256:4 3:256:4 3:128:4 2:256:8 2:256:4 3:256:4" 2 > $O/${TAG}_engines_sweep.txt 2>&1
+python $R/bench.py --steps 3 --warmup 1 --drain-between-steps --no-alt --no-latency --no-cpu-baseline --no-roofline > $O/${TAG}_bench_drain_between_steps.json 2> /dev/null
 cd /tmp
 # HBM traffic, both arithmetics merged into ONE file (kernel names differ: k_eng_fwd8 / k_eng_fwd ...)
 bash $R/tools/pmc_traffic.sh 128 8 > $O/${TAG}_hbm_split.json 2> $O/${TAG}_hbm_traffic_pmc.err
@@ -47,9 +48,9 @@ bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_
 NDP_GEMM_MODE=23 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_2launch_pmc.json
 NDP_GEMM_MODE=0 NDP_NN_MODE=0 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_bitwise_pmc.json
 bash $R/tools/pmc_mix.sh 256 12 > /dev/null 2>&1; cp $O/pmc_mix.json $O/${TAG}_instruction_mix_pmc.json 2> /dev/null
-# the two microbenchmarks behind the kernels' cost model: the matrix and the vector pipe of a SIMD side by side (they are not), issue
-# cost of the vector instructions the level kernels are made of
-for m in coexec valu_rates; do
+# the microbenchmarks behind the kernels' cost model: what hides in an MFMA gap (coexec2; round 4's coexec for the record), issue cost of
+# the vector instructions the level kernels are made of, the shapes of a tile's activation stores, v_fma_mix against the conversion sequence
+for m in coexec2 coexec valu_rates store_patterns mixprobe; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$m $R/tools/experiments/micro/$m.hip > /dev/null 2>&1 && /tmp/$m > $O/${TAG}_micro_$m.txt 2>&1
 done
 python $R/tools/latency_bench.py 5 > $O/${TAG}_latency_persistent_ab.txt 2>&1
