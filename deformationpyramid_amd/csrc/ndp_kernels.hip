@@ -36,15 +36,23 @@
 #ifdef NDP_PHASE_TIMING
 __device__ unsigned long long g_phase[96];
 __shared__ unsigned long long pt_acc[12];                 // per-workgroup accumulators (LDS: no global traffic per stamp)
+__shared__ unsigned long long pt_clk[2];                  // workgroup (0, 0): shader-cycle and 100 MHz real-time counters at its start
+// g_phase[94] / [95]: shader cycles / 100 MHz ticks that workgroup (0, 0) of the instrumented kernels lived -- their ratio x 0.1 is the
+// shader clock in GHz the launch actually ran at (tools/phase_timing.py prints it; under a power cap it is far from 2.4)
 #define PT_INIT                                           \
     do {                                                  \
         if (threadIdx.x < 12) pt_acc[threadIdx.x] = 0;    \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { pt_clk[0] = __builtin_readcyclecounter(); pt_clk[1] = __builtin_amdgcn_s_memrealtime(); } \
         __syncthreads();                                  \
     } while (0)
 #define PT_FLUSH(base)                                                                           \
     do {                                                                                         \
         __syncthreads();                                                                         \
         if (threadIdx.x < 12 && pt_acc[threadIdx.x]) atomicAdd(&g_phase[(base) + threadIdx.x], pt_acc[threadIdx.x]); \
+        if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) {                            \
+            atomicAdd(&g_phase[94], __builtin_readcyclecounter() - pt_clk[0]);                   \
+            atomicAdd(&g_phase[95], __builtin_amdgcn_s_memrealtime() - pt_clk[1]);               \
+        }                                                                                        \
     } while (0)
 #ifndef PT_TID
 #define PT_TID 0                                          /* the stamping thread (wave-specialised experiments look at other waves too) */

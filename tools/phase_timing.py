@@ -71,6 +71,8 @@ names = {0: "bwd2 load+lds", 1: "bwd2 barrier", 2: "bwd2 mfma(outer+gemm)+db", 3
          14: "fwd layer0", 16: "fwd layer1+h0 store", 17: "fwd barrier",
          19: "fwd barrier", 23: "fwd h2 store", 20: "fwd heads (mfma16)", 21: "fwd barrier"}
 print("per-tick ms [fwd nn loss bwd2 bwd1 upd]:", [round(x / ticks, 4) for x in ms])
+if buf[95]:            # workgroup (0, 0) of the instrumented kernels: shader cycles over 100 MHz ticks (one stage alone: that kernel's clock)
+    print(f"shader clock while the instrumented kernels ran: {buf[94] / buf[95] * 0.1:.2f} GHz  ({buf[94]} shader cycles / {buf[95]} ticks of 10 ns)")
 for grp, lo in (("bwd2", 0), ("fwd", 12), ("bwd1", 24)):
     tot = sum(buf[i] for i in range(lo, lo + 12))
     print(f"{grp}: {tot / tiles:.0f} cycles per tile (thread 0 wall)")
