@@ -553,6 +553,38 @@ def test_pair_means_is_the_correctly_rounded_mean(dev):
     assert got[3] == 0 and got[7] == 0
 
 
+def test_engine_load_computes_the_pair_means_of_its_jobs_in_one_launch(dev):
+    """A load job with n_src / n_tgt > 0 has its two cloud means computed BY the load call (k_pair_means_jobs: one launch for the
+    whole group, what register_batch relies on since round 5): the bits of ndp_pair_means, left in the job's buffer for the final warp,
+    and the slot centred with them -- next to a job of the same call that brings its means along."""
+    from deformationpyramid_amd import ops
+    from deformationpyramid_amd.engine import BatchedEngine, OptConfig
+    m = 2
+    pyr = seeded_pyramid(4, m=m, **VARIANTS["se3aa"])
+    eng = BatchedEngine(pyr.descs[0], OptConfig(m=m, iters=4, early_stop=False), 3, n_cap=256, t_cap=256, device=dev)
+    eng.park_all()
+    g = torch.Generator().manual_seed(2)
+    store = torch.zeros(m, eng.p_stride, device=dev)
+    store[:, :eng.P] = pyr.store[:, :eng.P].to(dev)
+    jobs, clouds = [], []
+    for b, (ns, nt) in enumerate([(8192, 5001), (700, 4097), (1234, 999)]):
+        src = (torch.rand(ns, 3, generator=g) * 3 - 1).to(dev)
+        tgt = (torch.rand(nt, 3, generator=g) * 0.2 + 5).to(dev)
+        S, T = min(200, ns), min(180, nt)
+        ps = torch.randperm(ns, generator=g)[:S].to(torch.int32).to(dev)
+        pt = torch.randperm(nt, generator=g)[:T].to(torch.int32).to(dev)
+        means = torch.full((8,), float("nan"), device=dev) if b != 1 else ops.pair_means(src, tgt)
+        jobs.append(dict(slot=b, params=store, K=0, S=S, T=T, src=src, tgt=tgt, perm_s=ps, perm_t=pt, means=means,
+                         n_src=ns if b != 1 else 0, n_tgt=nt if b != 1 else 0))
+        clouds.append((src, tgt, ps, pt, S, T, means))
+    eng.load_jobs(jobs)
+    torch.cuda.synchronize()
+    for b, (src, tgt, ps, pt, S, T, means) in enumerate(clouds):
+        want = ops.pair_means(src, tgt)
+        assert torch.equal(means, want), b
+        assert torch.equal(eng.pts[b, 0, :S], src[ps.long()] - want[:3]) and torch.equal(eng.tgt[b, :T], tgt[pt.long()] - want[4:7])
+
+
 def test_engine_load_jobs_centres_samples_and_resets_the_slot(dev):
     """k_eng_load against the torch statement of registration.py:150-164 (bit-exact: one subtraction per value)."""
     from deformationpyramid_amd import ops
