@@ -176,9 +176,10 @@ class _Lane:
                     p.result = out
                     p.release()
                 if ctx.sink is not None:
-                    for slot, p in done:
-                        ctx.sink(p.index, p.result, p.state)
-                        p.result = None
+                    with torch.cuda.stream(ctx.fin_stream):           # whatever the sink enqueues is ordered behind the final warp that
+                        for slot, p in done:                          # produced `warped` (it is NOT complete on the lane's stream)
+                            ctx.sink(p.index, p.result, p.state)
+                            p.result = None
         self.pending = handle
 
 
@@ -274,7 +275,9 @@ class Registration:
         the GPU, so the VALU-bound and latency-bound kernels of one overlap the MFMA-bound kernels of another.
         Returns [(warped, iter_cnt)] in input order.
         sink(i, warped, state): called (on the calling thread, in completion order) for every finished pair INSTEAD of keeping its
-        result -- a long stream of pairs then holds no more than the resident ones; the call returns None."""
+        result -- a long stream of pairs then holds no more than the resident ones; the call returns None.  The sink runs with the
+        final-warp stream current: GPU work it enqueues on `warped` is ordered behind the kernel that writes it; a reference it keeps
+        is safe to use once the call has returned."""
         pairs = list(pairs)
         if not pairs:
             return []
