@@ -413,7 +413,9 @@ def main():
     ap.add_argument("--pairs-per-step", type=int, default=0, help="pairs registered per step per GPU (default 32 x slots)")
     ap.add_argument("--chunk", type=int, default=0, help="ticks between host polls (0: 4, or 8 for the landmark configuration E whose ticks are "
                                                           "four times shorter -- the per-chunk host work of three lanes must fit under one chunk of GPU work)")
-    ap.add_argument("--engines", type=int, default=2, help="independent engines (HIP streams) per GPU, `slots` pairs each (3 x 128 until round 4)")
+    ap.add_argument("--engines", type=int, default=3, help="independent engines (HIP streams) per GPU, `slots` pairs each (3 x 128 until round 3, 2 x 256 in "
+                                                             "round 4; 3 x 256 since round 5: +2.7 % over 2 x 256 in three alternating 4-step runs each, "
+                                                             "profiles/r05_engines_sweep_long.txt)")
     ap.add_argument("--config", default="A", choices=list("ABCDE"),
                     help="SURVEY 8(d) workload: A NDP.yaml faithful (the headline line); B fixed work (= --fixed-work); C samples = 8192; "
                          "D Sim3/euler, 6000 samples of 24 856-pt clouds (shape transfer); E LNDP.yaml, 500 landmarks, m = 10")
