@@ -41,6 +41,26 @@ def test_struct_layouts_match_the_header():
     assert int(re.search(r"#define NDP_MAX_LOAD_JOBS (\d+)", header).group(1)) == _native.MAX_LOAD_JOBS
 
 
+def test_the_package_reads_no_environment_variable_and_variants_are_explicit():
+    """Nothing under deformationpyramid_amd/ reads the environment (the one WRITE is GPU_MAX_HW_QUEUES' default, before HIP starts): an
+    experiment build of the library can only be selected by _native.use_variant() -- which the measurement tools call for
+    NDP_HIP_LIB -- and not once the product library is loaded; bench.py refuses a selected variant without --allow-variant."""
+    import glob
+    from deformationpyramid_amd import _native
+    pkg = os.path.join(ROOT, "deformationpyramid_amd")
+    for path in glob.glob(os.path.join(pkg, "**", "*"), recursive=True):
+        if not path.endswith((".py", ".cpp", ".hip", ".inc", ".h")):
+            continue
+        text = open(path).read()
+        assert "getenv" not in text and "environ.get" not in text and "environ[" not in text, path
+    _native.lib()
+    with pytest.raises(_native.NdpError):
+        _native.use_variant("/nonexistent/libndp_variant.so")
+    assert _native.variant() is None
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert "N.variant() and not args.allow_variant" in bench and "tools" not in [ln for ln in bench.splitlines() if ln.startswith(("import", "from"))]
+
+
 def test_invalid_arguments_are_rejected_without_a_gpu():
     from deformationpyramid_amd import _native
     from deformationpyramid_amd.layout import LayerDesc
