@@ -779,6 +779,29 @@ def test_engine_matches_oracle_at_the_slot_geometry_bench_runs(dev, arith):
         assert torch.equal(eng.d2y[slot], eng.d2y[o]) and torch.equal(eng.idx_y[slot], eng.idx_y[o]), slot
 
 
+@pytest.mark.parametrize("G", [1, 4])
+def test_pipelined_forward_across_chunk_boundaries(dev, G):
+    """The split forward pipelines its workgroup's tiles (layer 0 of the next tile and the heads of the previous one ride in the
+    layers' MFMA gaps) and computes the encodings in chunks of eight tiles: 11 tiles per pair as ONE workgroup (a chunk of eight and a
+    chunk of three: the tile behind the boundary takes layer 0 in the open, the heads of the last tile of a chunk ride in the next
+    chunk's first layer 1) and as four workgroups of 3, 3, 3 and 2 tiles -- same steps, loss and points as the oracle, and both
+    partitions within round-off of each other (the forward's results do not depend on the partition: bit-identical points)."""
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=700, T=650, m=2, iters=4, early_stop=False, w_cd=1.0, trunc=1e9,
+                                          B=3, G=G, arith="split")
+    assert eng.G == G and eng.c_engine.gemm_mode == 7
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.level == 2 and st.total_steps == 8
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+        assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+    # one forward of the same state under both partitions: the activations a tile leaves do not depend on which workgroup ran it
+    outs = []
+    for g2 in (1, 4, 11):
+        e2, _, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=700, T=650, m=2, iters=1, early_stop=False, w_cd=1.0, trunc=1e9, B=1, G=g2, arith="split")
+        outs.append((e2.act[0, 1:, :704].clone(), e2.heads[0, :700].clone()))
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+
+
 def test_engine_nn_shapes_are_bit_identical(dev):
     """The three nearest-neighbour shapes of the engine must produce the same bits (losses, parameters) tick for tick."""
     runs = []
