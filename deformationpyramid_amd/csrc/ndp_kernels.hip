@@ -1942,7 +1942,7 @@ __device__ __forceinline__ void eng_update_param(const ndp_engine &e, int b, con
     }
     if (ns.decision != NDP_DEC_ADVANCE) {
         const float *gp = e.gpart + (size_t)b * e.G * e.p_stride;
-        float g = gp[i];
+        float g = __builtin_nontemporal_load(gp + i);
         int k = 1;
         for (; k + 8 <= e.G; k += 8) {                               // eight partials requested together, added in index order (batch 1 folds 32)
             float q[8];
