@@ -1244,6 +1244,10 @@ __device__ __forceinline__ void xcd_pair_block(int nvb, int B, int &b, int &vb) 
         vb = r % nvb;
     }
 }
+// Per-thread head rows in LDS (run-time row offsets live there) are NDP_LROW = 20 floats apart, not 16: the 16-byte accesses of an
+// eight-lane group then hit eight different bank quads and the scalar ones 4-way instead of 16-way ((16 t) mod 32 has two values,
+// (20 t) mod 32 eight) -- SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE of k_eng_loss 0.68 before.
+#define NDP_LROW 20
 #include "ndp_fwd_split.inc"
 
 // ------------------------------------------------------------------------------------------------
@@ -1580,7 +1584,7 @@ struct LossSmem {
     float red[256];
     int cnt[256], start[256];                                             // per-point bucket sizes / offsets
     int order[LG_CHUNK];                                                  // targets grouped by their nearest source point
-    __attribute__((aligned(16))) float rows[256 * NDP_NHMAX];             // per-thread head rows
+    __attribute__((aligned(16))) float rows[256 * NDP_LROW];              // per-thread head rows
 };
 // block reductions over the 256 ACTIVE threads of a workgroup (t: their index; the others only keep the barriers company -- the
 // persistent small-batch tick runs this stage on the lower half of its 512-thread workgroups)
@@ -1851,7 +1855,7 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
             const float den = (1.0f - nr) * nr;
             g_nr = e.w_reg * ((1.0f / (float)n) * (nr / (den > 1e-12f ? den : 1e-12f)));
         }
-        point_head_bwd(hcl, hrec + (size_t)p * NDP_HROW, xv, g, g_nr, rows + t * NDP_NHMAX, dO_row, &amax);
+        point_head_bwd(hcl, hrec + (size_t)p * NDP_HROW, xv, g, g_nr, rows + t * NDP_LROW, dO_row, &amax);
     } else if (p < e.n_cap) {
 #pragma unroll
         for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(dO_row + j) = make_float4(0.f, 0.f, 0.f, 0.f);
