@@ -2281,7 +2281,7 @@ extern "C" int ndp_debug_phase_read(unsigned long long *out64, int reset) {
 #ifndef NDP_BUILD_ID
 #define NDP_BUILD_ID "unversioned"
 #endif
-extern "C" int ndp_version(void) { return 200; }
+extern "C" int ndp_version(void) { return 202; }           // 201: ndp_load_job gained n_src / n_tgt (88 bytes), `means` in/out; 202: h2 as a plane image under gemm_mode 7
 extern "C" const char *ndp_last_error(void) { return g_err; }
 static const char k_build_tag[] = "NDP_BUILD_ID=" NDP_BUILD_ID;        // the loader finds this tag in the file without loading it
 extern "C" const char *ndp_build_id(void) { return k_build_tag + 13; }
@@ -2467,7 +2467,10 @@ extern "C" int ndp_engine_load(const ndp_engine *e, int tick, const ndp_load_job
         }
         lj.j[j] = q;
     }
-    if (any_means) hipLaunchKernelGGL(k_pair_means_jobs, dim3(2, n_jobs), dim3(1024), 0, (hipStream_t)stream, lj);
+    if (any_means) {
+        hipLaunchKernelGGL(k_pair_means_jobs, dim3(2, n_jobs), dim3(1024), 0, (hipStream_t)stream, lj);
+        HIP_TRY(hipGetLastError(), "k_pair_means_jobs launch");
+    }
     hipLaunchKernelGGL(k_eng_load, dim3(32, n_jobs), dim3(256), 0, (hipStream_t)stream, *e, tick & 1, lj);
     HIP_TRY(hipGetLastError(), "k_eng_load launch");
     return 0;
@@ -2632,10 +2635,19 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     bool persistent_fits = false;
     if (persistent) {
         if (int rc = set_smem((const void *)k_eng_tick_small, kSmemTickSmallBytes)) return rc;
-        int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_eng_tick_small, 512, kSmemTickSmallBytes) == hipSuccess &&
-            hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
-            persistent_fits = (long long)per_cu * cus >= (long long)e->B * e->G;
+        // (resident workgroups the device holds: queried once per device -- this is the batch-1 latency path, three HIP calls per
+        //  ndp_engine_run were host time on it)
+        static long long s_resident[64];                             // 0: not queried yet; -1: the query failed
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            if (s_resident[dev] == 0) {
+                int per_cu = 0, cus = 0;
+                s_resident[dev] = (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)k_eng_tick_small, 512, kSmemTickSmallBytes) == hipSuccess &&
+                                   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && per_cu > 0)
+                                      ? (long long)per_cu * cus : -1;
+            }
+            persistent_fits = s_resident[dev] >= (long long)e->B * e->G;
+        }
     }
     if (persistent && persistent_fits) {
         HIP_TRY(hipMemsetAsync(e->gmax + e->B, 0, sizeof(unsigned) * e->B, s), "pair barrier counters");

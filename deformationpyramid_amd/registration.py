@@ -51,6 +51,8 @@ class _Prepared:
         """Drop the device staging once the final warp has been enqueued (the allocator keeps the memory alive for
         the streams the tensors were recorded on)."""
         self.buf = self.store = self.perm_s = self.perm_t = self.tgt_pcd = self.ldmk_s = self.ldmk_t = None
+        self.src_pcd = self.means = None             # (the warp job that read them is enqueued; a per-pair device copy of the source
+                                                     #  and a 512-byte allocation per pair otherwise live until the batch call returns)
 
 
 class _PinRing:
@@ -86,7 +88,7 @@ class _PinRing:
 
 class _BatchCtx:
     """What the lanes of one register_batch call share."""
-    __slots__ = ("reg", "preps", "next_prepared", "fin_stream", "main", "chunk", "m", "exhausted", "handed_out", "total_slots", "sink")
+    __slots__ = ("reg", "preps", "next_prepared", "fin_stream", "main", "chunk", "m", "exhausted", "handed_out", "total_slots", "sink", "states")
 
     def __init__(self, reg, preps, next_prepared, fin_stream, main, chunk, m):
         self.reg, self.preps, self.next_prepared = reg, preps, next_prepared
@@ -94,6 +96,7 @@ class _BatchCtx:
         self.exhausted = False
         self.handed_out, self.total_slots = 0, 0          # pairs given to lanes so far / slots of all lanes (set once they exist)
         self.sink = None
+        self.states = [None] * len(preps)                 # final pair states by index (register_batch -> last_states)
 
 
 
@@ -161,6 +164,7 @@ class _Lane:
                 st = snap.state(slot)
                 del self.active[slot]
                 ctx.preps[i].state = st
+                ctx.states[i] = st
                 done.append((slot, ctx.preps[i]))
                 self.free.append(slot)
             if done:
@@ -180,6 +184,7 @@ class _Lane:
                         for slot, p in done:                          # produced `warped` (it is NOT complete on the lane's stream)
                             ctx.sink(p.index, p.result, p.state)
                             p.result = None
+                            ctx.preps[p.index] = None                 # a long stream holds the resident pairs only (its states: ctx.states)
         self.pending = handle
 
 
@@ -478,7 +483,7 @@ class Registration:
         for lane in lanes:
             main.wait_stream(lane.stream)
         main.wait_stream(fin_stream)
-        self.last_states = [p.state for p in preps]
+        self.last_states = ctx.states
         results = None if sink is not None else [(p.result, {lvl: int(p.state.evals_per_level[lvl]) for lvl in range(m)}) for p in preps]
         ctx.preps = ctx.next_prepared = None                     # nothing of this call stays reachable but the results
         return results

@@ -244,10 +244,13 @@ typedef struct ndp_engine {
     float *gpart;                    /* [B][G][p_stride]                                        */
     float *adam_m, *adam_v;          /* [B][p_stride]                                           */
     float *act;                      /* [B][3][n_cap][128] fp32 rows of h0, h1, h2 -- except under the default gemm_mode 7 (fused
-                                        split backward), where plane 1 holds h1 per 64-point tile as a PLANE IMAGE of the same size:
-                                        two [64][128] fp16 planes hi = fp16(2^6 h1) | lo = fp16(2^6 h1 - hi), rows of 256 bytes with
-                                        their 16-byte granules XOR-swizzled (csrc/ndp_fwd_split.inc: bf_swz) -- the backward's LDS
-                                        layout, written by the forward and pulled in by LDS-DMA                 */
+                                        split backward), where planes 1 and 2 hold h1 and (since ABI 202) h2 per 64-point tile as a
+                                        PLANE IMAGE of the same size: two [64][128] fp16 planes hi = fp16(2^6 h) | lo = fp16(2^6 h - hi),
+                                        rows of 256 bytes with their 16-byte granules XOR-swizzled (csrc/ndp_fwd_split.inc: bf_swz) --
+                                        the backward's LDS layout, written by the forward and pulled in by LDS-DMA; hi >= 2^-24
+                                        wherever h > 0 (it is read as the ReLU mask).  Every activation a split forward stores -- image
+                                        or fp32 row -- is the BOUNDED value: it saturates at 65504 / 64 = 1023.5 (the fp16 operand
+                                        range of the 2^6-scaled splits); this network's activations are O(1)        */
     float *heads;                    /* [B][n_cap][NDP_HROW]                                    */
     float *d2x; int *idx_x;          /* [B][n_cap]                                              */
     float *d2y; int *idx_y;          /* [B][t_cap]                                              */

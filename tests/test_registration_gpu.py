@@ -167,6 +167,30 @@ def test_register_batch_sink_receives_what_the_call_would_return(cfg, arith):
         assert torch.equal(w, got[i][0]) and got[i][1] == steps[i]
 
 
+def test_register_batch_sink_stream_holds_only_the_resident_pairs(cfg):
+    """A long stream through register_batch(sink=...) keeps device memory BOUNDED: a finished pair's staging -- the per-pair copy of the
+    source a host input gets, its means, its pyramid -- is dropped once its final warp is enqueued (until round 6 src_pcd and means of
+    EVERY pair of the call stayed alive until it returned: ~98 KB per 8192-point pair).  Host inputs, 72 pairs through 4 slots: the
+    allocated bytes seen by the sink after a third and after the whole stream differ by less than what ten pairs stage."""
+    from deformationpyramid_amd.config import Config
+    from deformationpyramid_amd.registration import Registration
+    from deformationpyramid_amd.synthetic import synthetic_pair
+    c = Config(cfg, samples=200, m=2, iters=6)
+    base = [synthetic_pair(60 + p, n_total=16384)[:2] for p in range(6)]            # ~8192-point clouds, on the HOST
+    pairs = [base[i % 6] for i in range(72)]
+    model = Registration(c)
+    seen = []
+
+    def sink(i, w, st):
+        seen.append(torch.cuda.memory_allocated())
+
+    torch.manual_seed(1)
+    assert model.register_batch(pairs, slots=4, engines=1, sink=sink) is None
+    assert len(seen) == 72 and len(model.last_states) == 72 and all(s is not None for s in model.last_states)
+    per_pair = base[0][0].numel() * 4                                               # one staged source copy
+    assert max(seen[60:]) - max(seen[16:28]) < 10 * per_pair, (seen[16:28], seen[60:])
+
+
 def test_surface_pair_metrics_sit_inside_the_references_seed_to_seed_distribution(cfg, golden, arith):
     """F10c: the reference's OWN distribution over process seeds on the eight surface pairs (eval_nolearned.py:22 seeds once, then
     registers pair after pair: 8 seeds x 8 pairs, seed means of full-EPE 6.06 .. 6.93 -- F10b's single draw per pair, 6.12, is a lucky

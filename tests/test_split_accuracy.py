@@ -65,8 +65,9 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
     eng.run_stages(0, 2)                                      # forward, nearest neighbours, loss / dL/dx'
     torch.cuda.synchronize()
     out["act_fwd"] = eng.act[0].cpu().clone()                 # h0, h1, h2
-    if (mode & 7) == 7 and not mode & 16:                     # the fused backward reads h1 as the forward's plane image, not as fp32 rows
+    if (mode & 7) == 7 and not mode & 16:                     # the fused backward reads h1 and (round 6) h2 as the forward's plane images, not as fp32 rows
         out["act_fwd"][1] = _decode_h1_image(out["act_fwd"][1])
+        out["act_fwd"][2] = _decode_h1_image(out["act_fwd"][2])
     out["heads"] = eng.heads[0].cpu().clone()
     out["dO"] = eng.dO[0].cpu().clone()
     eng.run_stages(3, 3)                                      # bwd2
@@ -296,10 +297,12 @@ def test_fused_backward_agrees_with_the_two_launch_backward(dev, tag, level):
     float64 -- every gradient tensor within 2e-6 of its own scale -- not bit equality.  Stage 4 of the fused tick launches nothing."""
     a = _run_tick_by_stages(dev, tag, 7, 2000, 2000, level, 20.0, G=2)          # fused (+ dz1 dump)
     b = _run_tick_by_stages(dev, tag, 7 | 16, 2000, 2000, level, 20.0, G=2)     # two launches
-    assert torch.equal(a["dO"], b["dO"]) and torch.equal(a["act_fwd"][0], b["act_fwd"][0]) and torch.equal(a["act_fwd"][2], b["act_fwd"][2])
-    # h1: the fused backward's forward leaves the split it fed to layer 2 (22 bits of 2^6 h1, as a plane image), the other the fp32 value
-    h1a, h1b = a["act_fwd"][1, :2000].double(), b["act_fwd"][1, :2000].double()
-    assert bool(((h1a - h1b).abs() <= 2.0 ** -21 * h1b.abs() + 2.0 ** -31).all()) and bool(((h1a > 0) == (h1b > 0)).all())
+    assert torch.equal(a["dO"], b["dO"]) and torch.equal(a["act_fwd"][0], b["act_fwd"][0])
+    # h1, h2: the fused backward's forward leaves the split it fed to layer 2 / to the heads (22 bits of 2^6 h, as a plane image), the
+    # other the fp32 value
+    for k in (1, 2):
+        ha, hb = a["act_fwd"][k, :2000].double(), b["act_fwd"][k, :2000].double()
+        assert bool(((ha - hb).abs() <= 2.0 ** -21 * hb.abs() + 2.0 ** -31).all()) and bool(((ha > 0) == (hb > 0)).all()), k
     assert torch.equal(a["g_bwd2"], a["g_all"])                                  # the fused stage 3 is the whole backward
     ka, kb = _kernel_outputs(a), _kernel_outputs(b)
     for k in ("dWh", "dbh", "dW2", "db2", "dz1", "dW1", "db1", "dW0", "db0"):
