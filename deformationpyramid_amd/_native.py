@@ -152,6 +152,7 @@ _SIGS = {
     "ndp_pyramid_fwd": [DP, I, I, V, I, V, I, V, V],
     "ndp_pyramid_fwd_batch": [DP, I, I, I, ctypes.POINTER(WarpJob), I, V],
     "ndp_pyramid_fwd_batch_split": [DP, I, I, I, ctypes.POINTER(WarpJob), I, V],
+    "ndp_pyramid_fwd_batch_split_tiles": [DP, I, I, I, ctypes.POINTER(WarpJob), I, I, V],
     "ndp_pair_means": [V, I, V, I, V, V],
     "ndp_nsfp_fwd": [V, V, I, V, V, V, V],
     "ndp_nsfp_bwd": [V, V, I, V, V, V, V, I, I, V],

@@ -2376,13 +2376,14 @@ extern "C" int ndp_pyramid_fwd(const ndp_layer_desc *desc, int m, int k0, const 
 }
 
 static int pyramid_fwd_batch_impl(const ndp_layer_desc *desc, int m, int k0, int p_stride, const ndp_warp_job *jobs, int n_jobs,
-                                  void *stream, bool split) {
+                                  void *stream, bool split, int tiles = P8_TILES) {
     if (int rc = check_desc(desc)) return rc;
     if (m < 1 || m > NDP_MAX_LEVELS || n_jobs < 0 || (n_jobs > 0 && !jobs) || p_stride < ndp_param_count(desc) || (p_stride & 3))
         return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch: bad arguments");
     if (split) { if (int rc = set_smem((const void *)k_pyramid_fwd8, kSmemPyr8Bytes)) return rc; }
     else if (int rc = set_smem((const void *)k_pyramid_fwd, kSmemFwdBytes)) return rc;
-    const int per_wg = NDP_TILE * (split ? P8_TILES : NDP_PYR_TILES);                          // points per workgroup
+    if (split && (tiles < 1 || tiles > P8_TILES_MAX)) return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch_split_tiles: tiles per workgroup must be 1..8");
+    const int per_wg = NDP_TILE * (split ? tiles : NDP_PYR_TILES);                             // points per workgroup
     for (int j0 = 0; j0 < n_jobs; j0 += NDP_MAX_WARP_JOBS) {
         WarpJobs wj;
         memset(&wj, 0, sizeof wj);
@@ -2397,7 +2398,7 @@ static int pyramid_fwd_batch_impl(const ndp_layer_desc *desc, int m, int k0, int
             if (wgs > max_wgs) max_wgs = wgs;
         }
         if (!cnt) continue;
-        if (split) hipLaunchKernelGGL(k_pyramid_fwd8, dim3(max_wgs, cnt), dim3(512), kSmemPyr8Bytes, (hipStream_t)stream, *desc, m, k0, p_stride, wj);
+        if (split) hipLaunchKernelGGL(k_pyramid_fwd8, dim3(max_wgs, cnt), dim3(512), kSmemPyr8Bytes, (hipStream_t)stream, *desc, m, k0, p_stride, wj, tiles);
         else hipLaunchKernelGGL(k_pyramid_fwd, dim3(max_wgs, cnt), dim3(256), kSmemFwdBytes, (hipStream_t)stream, *desc, m, k0, p_stride, wj);
         HIP_TRY(hipGetLastError(), "k_pyramid_fwd launch");
     }
@@ -2414,6 +2415,12 @@ extern "C" int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, 
 extern "C" int ndp_pyramid_fwd_batch_split(const ndp_layer_desc *desc, int m, int k0, int p_stride,
                                            const ndp_warp_job *jobs, int n_jobs, void *stream) {
     return pyramid_fwd_batch_impl(desc, m, k0, p_stride, jobs, n_jobs, stream, true);
+}
+// ... with `tiles` 64-point tiles per workgroup (1..8; the entry above: 4).  More tiles per workgroup = fewer weight prologues per cloud
+// (less CU-time per cloud, the batched engine's choice) at a longer latency of the launch (fewer, longer workgroups).  Same bits.
+extern "C" int ndp_pyramid_fwd_batch_split_tiles(const ndp_layer_desc *desc, int m, int k0, int p_stride,
+                                                 const ndp_warp_job *jobs, int n_jobs, int tiles, void *stream) {
+    return pyramid_fwd_batch_impl(desc, m, k0, p_stride, jobs, n_jobs, stream, true, tiles);
 }
 
 extern "C" int ndp_pair_means(const float *src, int n_src, const float *tgt, int n_tgt, float *means, void *stream) {

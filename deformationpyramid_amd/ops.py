@@ -88,10 +88,11 @@ def pyramid_fwd(desc: LayerDesc, m, k0, store, x):
     return out
 
 
-def pyramid_fwd_batch(desc: LayerDesc, m, k0, jobs, device=None, split=False):
+def pyramid_fwd_batch(desc: LayerDesc, m, k0, jobs, device=None, split=False, tiles=None):
     """jobs: [(store [m,p_stride], x [n,3], shift_in [>=3] | None, shift_out [>=3] | None)] -> [x_out [n,3]]: every
     cloud through its whole pyramid in ONE launch per 32 jobs; x_out = pyramid(x - shift_in) + shift_out.
-    split: the engine's fp16-split arithmetic (k_pyramid_fwd8) instead of the fp32 MFMA (bitwise the level chain)."""
+    split: the engine's fp16-split arithmetic (k_pyramid_fwd8) instead of the fp32 MFMA (bitwise the level chain).
+    tiles (split only): 64-point tiles per workgroup, 1..8 (default 4; the batched engine passes 8: half the weight prologues)."""
     if not jobs:
         return []
     arr = (N.WarpJob * len(jobs))()
@@ -115,6 +116,10 @@ def pyramid_fwd_batch(desc: LayerDesc, m, k0, jobs, device=None, split=False):
         q.n = x.shape[0]
     cd = desc.c_struct()
     dev = device if device is not None else jobs[0][1].device
+    if split and tiles is not None:
+        N.check(N.lib().ndp_pyramid_fwd_batch_split_tiles(ctypes.byref(cd), int(m), int(k0), int(stride), arr, len(jobs), int(tiles),
+                                                          N.stream_ptr(dev)), "ndp_pyramid_fwd_batch_split_tiles")
+        return outs
     fn = N.lib().ndp_pyramid_fwd_batch_split if split else N.lib().ndp_pyramid_fwd_batch
     N.check(fn(ctypes.byref(cd), int(m), int(k0), int(stride), arr, len(jobs), N.stream_ptr(dev)), "ndp_pyramid_fwd_batch")
     return outs

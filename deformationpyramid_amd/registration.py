@@ -138,7 +138,7 @@ class _Lane:
             i, p = nxt
             slot = self.free.pop()
             if slot in self.fin_done:
-                self.stream.wait_event(self.fin_done.pop(slot))   # the previous tenant's final warp read these params
+                self.stream.wait_event(self.fin_done.pop(slot))   # the previous tenant's parameters have been copied out for its final warp
             jobs.append(p.load_job(slot))
             self.active[slot] = (i, self.seq)            # snapshots >= seq see this pair in the slot
         if jobs:
@@ -171,9 +171,8 @@ class _Lane:
                 # the snapshot proves every tick that touched these slots has completed: the final warp
                 # needs no dependency on the lane's stream, only the slots' refill must wait for it
                 with torch.cuda.stream(ctx.fin_stream):
-                    outs = ctx.reg._finish(eng, done, freeze=True)
                     ev = torch.cuda.Event()
-                    ev.record(ctx.fin_stream)
+                    outs = ctx.reg._finish(eng, done, freeze=True, frozen=lambda: ev.record(ctx.fin_stream))
                 for (slot, p), out in zip(done, outs):
                     self.fin_done[slot] = ev
                     out.record_stream(ctx.main)
@@ -637,14 +636,22 @@ class Registration:
             self._engines[lane] = BatchedEngine(desc, cfg, B, n_cap, t_cap, self._dev(), gemm_mode=self.gemm_mode, nn_mode=self.nn_mode, nn_matrix=self.nn_matrix)
         return self._engines[lane]
 
-    def _finish(self, eng, done, freeze=False):
+    def _finish(self, eng, done, freeze=False, frozen=None):
         """registration.py:253-262 for every (slot, prepared pair) of `done`, in one launch: ALL source points through
         the optimised pyramid (centring by the source mean and adding the target mean happen in the kernel).
-        freeze=True first snapshots the slots' parameters so that the slots can be refilled at once."""
+        freeze=True first snapshots the slots' parameters -- ONE gathering copy for all of them (round 6; until then a clone per
+        pair) -- so that the slots can be refilled at once: `frozen()` is called between the copy and the warp launch (the batched
+        lanes record the event their refills wait for there: a refill waits for the copy, not for the warp).  The batched path
+        (freeze) also takes the warp's throughput shape, eight tiles per workgroup."""
         c = self.config
-        jobs = []
-        for slot, prep in done:
-            store = eng.params[slot].clone() if freeze else eng.params[slot]      # [m, p_stride] on device
-            jobs.append(prep.warp_job(store))
+        split = bool(eng.gemm_mode & 1)
+        if freeze:
+            stores = torch.stack([eng.params[slot] for slot, _ in done])          # [len(done), m, p_stride]
+            if frozen is not None:
+                frozen()
+            jobs = [prep.warp_job(stores[k]) for k, (_, prep) in enumerate(done)]
+        else:
+            jobs = [prep.warp_job(eng.params[slot]) for slot, prep in done]
         # the final warp runs in the engine's arithmetic: fp16-split contractions with gemm_mode & 1, the fp32 MFMA otherwise
-        return ops.pyramid_fwd_batch(done[0][1].desc, c.m, c.k0, jobs, device=self._dev(), split=bool(eng.gemm_mode & 1))
+        return ops.pyramid_fwd_batch(done[0][1].desc, c.m, c.k0, jobs, device=self._dev(), split=split,
+                                     tiles=8 if (freeze and split) else None)

@@ -93,6 +93,10 @@ int ndp_pyramid_fwd_batch(const ndp_layer_desc *desc, int m, int k0, int p_strid
  * saturates (layer 0's pre-activation at 65504).                                                                                  */
 int ndp_pyramid_fwd_batch_split(const ndp_layer_desc *desc, int m, int k0, int p_stride,
                                 const ndp_warp_job *jobs, int n_jobs, void *stream);
+/* the same with `tiles` (1..8) 64-point tiles per workgroup instead of 4: fewer weight prologues per cloud, longer workgroups (the
+   batched engine's throughput shape; identical results) */
+int ndp_pyramid_fwd_batch_split_tiles(const ndp_layer_desc *desc, int m, int k0, int p_stride,
+                                      const ndp_warp_job *jobs, int n_jobs, int tiles, void *stream);
 
 /* Per-cloud means (registration.py:150-153: src_pcd.mean(dim=0), tgt_pcd.mean(dim=0)); means[0..2] = source,
  * means[4..6] = target (means[3], means[7] = 0).  Accumulated in double in a fixed order, rounded once.   */

@@ -31,6 +31,10 @@ cfg = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _modes import from_env
 model = Registration(cfg, **from_env())
+if os.environ.get("NDP_PT_G"):            # level-kernel workgroups per pair forced (e.g. B = 128 with G = 1: half of the CUs idle)
+    import deformationpyramid_amd.registration as _R
+    _BE, _G = _R.BatchedEngine, int(os.environ["NDP_PT_G"])
+    _R.BatchedEngine = lambda *a, **k: _BE(*a, G=_G, **k)
 preps = [model._prepare(*[t.to(dev) for t in synthetic_pair(i)[:2]], None) for i in range(B)]
 eng = model._engine(B, preps[0])
 eng.load_jobs([p.load_job(b) for b, p in enumerate(preps)][:16])
