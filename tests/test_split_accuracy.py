@@ -66,8 +66,8 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
     torch.cuda.synchronize()
     out["act_fwd"] = eng.act[0].cpu().clone()                 # h0, h1, h2
     if (mode & 7) == 7 and not mode & 16:                     # the fused backward reads h1 and (round 6) h2 as the forward's plane images, not as fp32 rows
-        out["act_fwd"][1] = _decode_h1_image(out["act_fwd"][1])
-        out["act_fwd"][2] = _decode_h1_image(out["act_fwd"][2])
+        out["act_fwd"][1] = _decode_plane_image(out["act_fwd"][1])
+        out["act_fwd"][2] = _decode_plane_image(out["act_fwd"][2])
     out["heads"] = eng.heads[0].cpu().clone()
     out["dO"] = eng.dO[0].cpu().clone()
     eng.run_stages(3, 3)                                      # bwd2
@@ -82,8 +82,8 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
     return out
 
 
-def _decode_h1_image(act1):
-    """The h1 plane image the split forward leaves for the FUSED backward (gemm_mode 7): per 64-point tile 32 KB -- the footprint of the
+def _decode_plane_image(act1):
+    """A plane image (h1; since round 6 also h2) the split forward leaves for the FUSED backward (gemm_mode 7): per 64-point tile 32 KB -- the footprint of the
     fp32 rows it replaces -- holding two fp16 planes [64][128], hi = fp16(2^6 h1) and lo = fp16(2^6 h1 - hi), each row's sixteen
     16-byte granules XOR-swizzled (ndp_fwd_split.inc: bf_swz).  -> [rows][128] float32 (hi + lo carries 22 bits: exact in fp32)."""
     rows = act1.shape[0] // 64 * 64

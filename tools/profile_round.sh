@@ -31,7 +31,7 @@ python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_bench/*.db | head -1) $O/
 NDP_GEMM_MODE=23 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof_tick_2launch -o tick -- python $R/tools/tick_bench.py 128 24 > $O/${TAG}_prof_tick_2launch.log 2>&1
 python $R/tools/rocprof_summary.py $(ls $O/${TAG}_prof_tick_2launch/*.db | head -1) $O/${TAG}_tick_kernel_stats_2launch.csv > /dev/null
 # what the second and third engine buy
-bash $R/tools/experiments/sweep3.sh "2:256:4 3:256:4 3:128:4 2:256:8 2:256:4 3:256:4" 2 > $O/${TAG}_engines_sweep.txt 2>&1
+bash $R/tools/experiments/sweep3.sh "2:256:4 3:256:4 2:256:4 3:256:4" 2 > $O/${TAG}_engines_sweep.txt 2>&1
 python $R/bench.py --steps 3 --warmup 1 --drain-between-steps --no-alt --no-latency --no-cpu-baseline --no-roofline > $O/${TAG}_bench_drain_between_steps.json 2> /dev/null
 cd /tmp
 # HBM traffic, both arithmetics merged into ONE file (kernel names differ: k_eng_fwd8 / k_eng_fwd ...)
@@ -50,7 +50,8 @@ NDP_GEMM_MODE=0 NDP_NN_MODE=0 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; c
 bash $R/tools/pmc_mix.sh 256 12 > /dev/null 2>&1; cp $O/pmc_mix.json $O/${TAG}_instruction_mix_pmc.json 2> /dev/null
 # the microbenchmarks behind the kernels' cost model: what hides in an MFMA gap (coexec2; round 4's coexec for the record), issue cost of
 # the vector instructions the level kernels are made of, the shapes of a tile's activation stores, v_fma_mix against the conversion sequence
-for m in coexec2 coexec valu_rates store_patterns mixprobe; do
+python $R/tools/experiments/micro/coexec2_gen.py > /tmp/coexec2.hip && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/coexec2 /tmp/coexec2.hip > /dev/null 2>&1 && /tmp/coexec2 > $O/${TAG}_micro_coexec2.txt 2>&1   # (generated: not tracked)
+for m in coexec valu_rates store_patterns mixprobe; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/$m $R/tools/experiments/micro/$m.hip > /dev/null 2>&1 && /tmp/$m > $O/${TAG}_micro_$m.txt 2>&1
 done
 python $R/tools/latency_bench.py 5 > $O/${TAG}_latency_persistent_ab.txt 2>&1
