@@ -251,8 +251,8 @@ typedef struct ndp_engine {
                                         split backward), where planes 1 and 2 hold h1 and (since ABI 202) h2 per 64-point tile as a
                                         PLANE IMAGE of the same size: two [64][128] fp16 planes hi = fp16(2^6 h) | lo = fp16(2^6 h - hi),
                                         rows of 256 bytes with their 16-byte granules XOR-swizzled (csrc/ndp_fwd_split.inc: bf_swz) --
-                                        the backward's LDS layout, written by the forward and pulled in by LDS-DMA; hi >= 2^-24
-                                        wherever h > 0 (it is read as the ReLU mask).  Every activation a split forward stores -- image
+                                        the backward's LDS layout, written by the forward and pulled in by LDS-DMA; the ReLU mask is
+                                        hi's SIGN BIT: hi = -0 where the pre-activation is <= 0, hi >= +0 where it is positive.  Every activation a split forward stores -- image
                                         or fp32 row -- is the BOUNDED value: it saturates at 65504 / 64 = 1023.5 (the fp16 operand
                                         range of the 2^6-scaled splits); this network's activations are O(1)        */
     float *heads;                    /* [B][n_cap][NDP_HROW]                                    */

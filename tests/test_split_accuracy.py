@@ -95,9 +95,10 @@ def _decode_plane_image(act1):
     planes = torch.gather(img, 3, idx)
     out = torch.full_like(act1, float("nan"))
     val = (planes[:, 0] + planes[:, 1]) / 64.0
-    # the ReLU mask is the HI plane's sign (hi is kept >= 2^-24 wherever h1 > 0; for 2^6 h1 < 2^-25 lo then rounds to -2^-24 and the
-    # sum to zero): such an element decodes to a positive value below everything else
-    val = torch.where((planes[:, 0] > 0) & (val <= 0), torch.full_like(val, 2.0 ** -40), val)
+    # the ReLU mask is the HI plane's SIGN BIT (round 6: hi = -0 where the pre-activation is <= 0, hi >= +0 where it is positive -- a
+    # positive activation below fp16's range has hi = +0 and its value in lo, or nothing at all): a positive element whose parts sum to
+    # zero decodes to a positive value below everything else
+    val = torch.where(~torch.signbit(planes[:, 0]) & (val <= 0), torch.full_like(val, 2.0 ** -40), val)
     out[:rows] = val.reshape(rows, 128)
     return out
 
