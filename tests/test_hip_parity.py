@@ -507,6 +507,11 @@ def test_pyramid_fwd_batch_split_matches_the_fp32_kernel_and_the_oracle(dev, tag
     got = ops.pyramid_fwd_batch(pyrs[0].descs[0], m, K0, jobs, split=True)
     for a, b in zip(got, ref):
         assert a.shape == b.shape and torch.isfinite(a).all()
+    # ndp_pyramid_fwd_batch_split_tiles: the tiles per workgroup change the launch geometry only -- 8 (what register_batch passes), 1
+    # and 5 give the bits of the default 4
+    for tiles in (8, 1, 5):
+        alt = ops.pyramid_fwd_batch(pyrs[0].descs[0], m, K0, jobs, split=True, tiles=tiles)
+        assert all(torch.equal(a, b) for a, b in zip(alt, got)), tiles
     err = torch.cat([(a - b).abs().max(dim=1).values for a, b in zip(got, ref)])
     if "6d" in tag:
         # 6D rotations are a Gram-Schmidt of two RAW head vectors: where a point's two vectors come out nearly parallel the map is
