@@ -360,9 +360,11 @@ __device__ __forceinline__ float block_sum_256(float v, float *scratch /* >= 256
 __device__ __forceinline__ void point_head_bwd(const HeadCfg &hc, const float *heads_row /*global, NDP_HROW*/,
                                                const float *x, const float *g, float g_nr, float *lds_row,
                                                float *dO_row /*global*/, float *amax = nullptr /* max |dO| of the row */) {
+    if (heads_row) {                                 // (nullptr: the caller has already brought the row into lds_row)
 #pragma unroll
-    for (int j = 0; j < NDP_NHMAX; j += 4)
-        *reinterpret_cast<float4 *>(lds_row + j) = *reinterpret_cast<const float4 *>(heads_row + j);
+        for (int j = 0; j < NDP_NHMAX; j += 4)
+            *reinterpret_cast<float4 *>(lds_row + j) = *reinterpret_cast<const float4 *>(heads_row + j);
+    }
     PointHead c;
     float out[3];
     head_warp_fwd(hc, lds_row, x, c, out);

@@ -1623,13 +1623,18 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
     int *cnt = sm_.cnt, *start = sm_.start, *order = sm_.order;
     PT_INIT;
     PT_DECL;
-    const ndp_pair_state st = e.state[parity * e.B + b];
+    // Only the scalar fields are read here; the per-level array travels memory to memory in the one thread that writes the next state
+    // (a by-value copy of the struct parked 80 bytes in scratch in EVERY thread of the launch, behind a wait for its loads: round 6).
+    const ndp_pair_state *stp = e.state + (size_t)parity * e.B + b;
+    struct { int level, iter, break_counter, adam_t, cur, total_steps, total_evals; double loss_prev; } st;
+    st.level = stp->level; st.iter = stp->iter; st.break_counter = stp->break_counter; st.adam_t = stp->adam_t; st.cur = stp->cur;
+    st.total_steps = stp->total_steps; st.total_evals = stp->total_evals; st.loss_prev = stp->loss_prev;
+    const ndp_pair_geom gm = e.geom[b];                                  // (requested next to the state, not behind the test on it)
     ndp_pair_state *nst = e.state + (size_t)(parity ^ 1) * e.B + b;
     if (st.level >= e.m) {
-        if (vb == nvb - 1 && t == 0 && act) { ndp_pair_state c = st; c.decision = NDP_DEC_IDLE; *nst = c; }
+        if (vb == nvb - 1 && t == 0 && act) { *nst = *stp; nst->decision = NDP_DEC_IDLE; }
         return;
     }
-    const ndp_pair_geom gm = e.geom[b];
     const int n = gm.K + gm.S;
     const float *x_out = e.pts + ((size_t)b * 2 + (st.cur ^ 1)) * e.n_cap * 3;
     const float *ldmk_t = e.ldmk_t + (size_t)b * e.n_cap * 3;
@@ -1701,28 +1706,28 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
                 }
             }
             const int decision = stop ? NDP_DEC_ADVANCE : (st.iter + 1 >= e.iters ? NDP_DEC_STEP_ADVANCE : NDP_DEC_STEP);
-            ndp_pair_state c = st;
-            c.loss = loss;
-            c.decision = decision;
-            c.total_evals = st.total_evals + 1;
-            c.step_level = st.level;
-            c.step_t = st.adam_t + 1;
-            if (decision != NDP_DEC_ADVANCE) c.total_steps = st.total_steps + 1;
+            // the next state = this one with the fields below replaced, written field by field (a private copy of the struct with its
+            // per-level array lived in scratch, and every thread of every workgroup paid the 64-byte store that initialised it)
+            *nst = *stp;
+            nst->loss = loss;
+            nst->decision = decision;
+            nst->total_evals = st.total_evals + 1;
+            nst->step_level = st.level;
+            nst->step_t = st.adam_t + 1;
+            if (decision != NDP_DEC_ADVANCE) nst->total_steps = st.total_steps + 1;
             if (decision == NDP_DEC_STEP) {
-                c.iter = st.iter + 1;
-                c.adam_t = st.adam_t + 1;
-                c.break_counter = bc;
-                c.loss_prev = lp;
+                nst->iter = st.iter + 1;
+                nst->adam_t = st.adam_t + 1;
+                nst->break_counter = bc;
+                nst->loss_prev = lp;
             } else {                                       // registration.py:242-249 + :179-180
-                c.level = st.level + 1;
-                c.iter = 0;
-                c.adam_t = 0;
-                c.break_counter = 0;
-                c.loss_prev = 1e6;
-                c.cur = st.cur ^ 1;
+                nst->level = st.level + 1;
+                nst->iter = 0;
+                nst->adam_t = 0;
+                nst->break_counter = 0;
+                nst->loss_prev = 1e6;
+                nst->cur = st.cur ^ 1;
             }
-            *nst = c;
-            // (written straight to memory: a run-time index into the private copy would push it to scratch)
             if (decision != NDP_DEC_STEP) nst->evals_per_level[st.level] = st.iter + 1;
         }
         PT(4);
@@ -1734,7 +1739,14 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
     if (vb * 256 >= n) return;
     float *dO_row = e.dO + ((size_t)b * e.n_cap + p) * NDP_NHMAX;
     float w[3] = {0.f, 0.f, 0.f}, g[3] = {0.f, 0.f, 0.f};
-    if (p < n) { w[0] = x_out[3 * p]; w[1] = x_out[3 * p + 1]; w[2] = x_out[3 * p + 2]; }
+    // Requested up front, next to the warped point: the point's level input, which only the head backward at the end needs -- behind
+    // the scatter it and the head record (below) were one more global round trip in the open (round 6).
+    float xv[3] = {0.f, 0.f, 0.f};
+    if (p < n) {
+        const float *xin = e.pts + ((size_t)b * 2 + st.cur) * e.n_cap * 3 + 3 * p;
+        w[0] = x_out[3 * p]; w[1] = x_out[3 * p + 1]; w[2] = x_out[3 * p + 2];
+        xv[0] = xin[0]; xv[1] = xin[1]; xv[2] = xin[2];
+    }
     const int i_self = p - gm.K;                     // sample index (negative for landmarks)
     // Every phase below is a chain of 1-2 us global round trips (tools/phase_timing.py), so what can be requested now is: the
     // chunk's nearest-source indices (local point of target c0 + t + 256 k, -1: not ours) travel with the row partials.
@@ -1766,6 +1778,15 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
             for (int a = 0; a < 3; ++a) g[a] = (w[a] - yy[a]) * inv;
         }
     }
+    // the head record travels under the counting sort's first passes (16 registers that the row fold above had no room for)
+    static_assert(NDP_NHMAX == 16, "four float4 per head row");
+    float4 hr0 = make_float4(0.f, 0.f, 0.f, 0.f), hr1 = hr0, hr2 = hr0, hr3 = hr0;
+    if (p < n) {
+        const float4 *hsrc = reinterpret_cast<const float4 *>(hrec + (size_t)p * NDP_HROW);
+        hr0 = hsrc[0]; hr1 = hsrc[1]; hr2 = hsrc[2]; hr3 = hsrc[3];
+    }
+#define LOSS_HR_STORE() do { if (p < n) { float4 *hd_ = reinterpret_cast<float4 *>(rows + t * NDP_LROW); hd_[0] = hr0; hd_[1] = hr1; hd_[2] = hr2; hd_[3] = hr3; } } while (0)
+    if (!scatter) LOSS_HR_STORE();
     PT(0);
     if (scatter) {
         // Targets whose nearest source point belongs to this workgroup, grouped per point by a counting
@@ -1805,6 +1826,7 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
             const int my_start = start[t] - mine;
             __syncthreads();
             if (act) start[t] = my_start;                                 // becomes the fill cursor
+            if (c0 == 0) LOSS_HR_STORE();
             __syncthreads();
             PT(2);
             // pass 2: fill
@@ -1847,15 +1869,13 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
     // ---- per-point head backward: dO = mlp_scale * dL/d(scaled head outputs); zero rows pad the last tile
     float amax = 0.f;
     if (p < n) {
-        const float *xin = e.pts + ((size_t)b * 2 + st.cur) * e.n_cap * 3 + 3 * p;
-        const float xv[3] = {xin[0], xin[1], xin[2]};
         float g_nr = 0.f;
         if (use_reg) {                                   // d/dnr of w_reg * mean(-log(1 - nr)), torch's BCE backward clamp
-            const float nr = 1.0f / (1.0f + expf(-hrec[(size_t)p * NDP_HROW + hcl.row_nr]));
+            const float nr = 1.0f / (1.0f + expf(-rows[t * NDP_LROW + hcl.row_nr]));
             const float den = (1.0f - nr) * nr;
             g_nr = e.w_reg * ((1.0f / (float)n) * (nr / (den > 1e-12f ? den : 1e-12f)));
         }
-        point_head_bwd(hcl, hrec + (size_t)p * NDP_HROW, xv, g, g_nr, rows + t * NDP_LROW, dO_row, &amax);
+        point_head_bwd(hcl, nullptr, xv, g, g_nr, rows + t * NDP_LROW, dO_row, &amax);
     } else if (p < e.n_cap) {
 #pragma unroll
         for (int j = 0; j < NDP_NHMAX; j += 4) *reinterpret_cast<float4 *>(dO_row + j) = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1876,7 +1896,7 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
     PT_FLUSH(36);
 }
 
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, 5)                     // five waves per SIMD: what the 31 KB of LDS allow (<= 96 registers)
 k_eng_loss(ndp_engine e, int parity) {
     __shared__ LossSmem sm_;
     int b, vb;
