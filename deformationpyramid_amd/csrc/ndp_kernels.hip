@@ -1995,6 +1995,7 @@ k_eng_update(ndp_engine e, int parity) {
 }
 
 #include "ndp_tick_small.inc"
+#include "ndp_generic.inc"
 
 // ------------------------------------------------------------------------------------------------
 // Neural scene-flow prior baseline (nets.py:256-292): one launch per layer
@@ -2270,8 +2271,8 @@ static int hip_fail(hipError_t e, const char *what) {
 
 static int check_desc(const ndp_layer_desc *d) {
     if (!d) return fail(NDP_E_INVALID, "null layer descriptor");
-    if (d->width != NDP_W || d->n_hidden != 2)
-        return fail(NDP_E_UNSUPPORTED, "kernels are specialised for width=128, depth=3");
+    if (gen_is_generic(*d) && !gen_supported(*d))                       // 128 / 3: the MFMA kernels; anything else: csrc/ndp_generic.inc
+        return fail(NDP_E_UNSUPPORTED, "width must be 1..256 and depth 1..4 (width=128, depth=3 run on the MFMA kernels, the rest on the generic fp32 kernels)");
     if (d->motion < 0 || d->motion > 2) return fail(NDP_E_INVALID, "bad motion type");
     if (d->motion != NDP_MOTION_SFLOW && (d->rotfmt < NDP_ROT_AXIS_ANGLE || d->rotfmt > NDP_ROT_6D))
         return fail(NDP_E_INVALID, "bad rotation_format");
@@ -2326,6 +2327,13 @@ extern "C" int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, in
     job.nonrig = desc->nonrigidity ? nonrig_out : nullptr;
     job.n = n; job.n_tiles = (n + NDP_TILE - 1) / NDP_TILE; job.plane = job.n_tiles * NDP_TILE;
     job.tile0 = 0; job.tile_step = 0;
+    if (gen_is_generic(*desc)) {                                         // act: [n_hidden + 1][plane][width]
+        if (int rc = set_smem((const void *)k_gen_level_fwd, kSmemGenFwdMax)) return rc;
+        hipLaunchKernelGGL(k_gen_level_fwd, dim3(job.n_tiles < 1024 ? job.n_tiles : 1024), dim3(256), gen_fwd_floats(desc->width) * 4, (hipStream_t)stream,
+                           make_head_cfg(*desc), *desc, job);
+        HIP_TRY(hipGetLastError(), "k_gen_level_fwd launch");
+        return 0;
+    }
     if (int rc = set_smem((const void *)k_level_fwd, kSmemFwdBytes)) return rc;
     // one tile per workgroup: measured best for the final all-point warp (more tiles per workgroup save weight
     // loads but lengthen the warp, and throughput dropped 478 -> 438 pairs/s at 4 tiles per workgroup)
@@ -2356,11 +2364,17 @@ extern "C" int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, in
                                sizeof(float) * (size_t)(n_part - job.n_tiles) * p_stride, s), "memset");
         n_part = job.n_tiles;
     }
-    if (int rc = set_smem((const void *)k_level_bwd2, kSmemBwdBytes)) return rc;
-    if (int rc = set_smem((const void *)k_level_bwd1, kSmemBwdBytes)) return rc;
     const HeadCfg hc = make_head_cfg(*desc);
     hipLaunchKernelGGL(k_head_bwd, dim3((job.plane + 255) / 256), dim3(256), 0, s, hc, x, heads, g,
                        desc->nonrigidity ? g_nr : nullptr, n, job.plane, dO_work);
+    if (gen_is_generic(*desc)) {
+        if (int rc = set_smem((const void *)k_gen_level_bwd, kSmemGenBwdMax)) return rc;
+        hipLaunchKernelGGL(k_gen_level_bwd, dim3(n_part), dim3(256), gen_bwd_floats(desc->width) * 4, s, hc, *desc, job, p_stride);
+        HIP_TRY(hipGetLastError(), "generic level backward launch");
+        return 0;
+    }
+    if (int rc = set_smem((const void *)k_level_bwd2, kSmemBwdBytes)) return rc;
+    if (int rc = set_smem((const void *)k_level_bwd1, kSmemBwdBytes)) return rc;
     job.dz_plane = act + 2 * (size_t)job.plane * NDP_W;
     job.h_plane = act + (size_t)job.plane * NDP_W;
     bwd_job_ndp_layer2(job, hc.nh);
@@ -2400,10 +2414,12 @@ static int pyramid_fwd_batch_impl(const ndp_layer_desc *desc, int m, int k0, int
     if (int rc = check_desc(desc)) return rc;
     if (m < 1 || m > NDP_MAX_LEVELS || n_jobs < 0 || (n_jobs > 0 && !jobs) || p_stride < ndp_param_count(desc) || (p_stride & 3))
         return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch: bad arguments");
-    if (split) { if (int rc = set_smem((const void *)k_pyramid_fwd8, kSmemPyr8Bytes)) return rc; }
+    const bool generic = gen_is_generic(*desc);                        // one arithmetic there: `split` and `tiles` select nothing
+    if (generic) { if (int rc = set_smem((const void *)k_gen_pyramid_fwd, kSmemGenFwdMax)) return rc; }
+    else if (split) { if (int rc = set_smem((const void *)k_pyramid_fwd8, kSmemPyr8Bytes)) return rc; }
     else if (int rc = set_smem((const void *)k_pyramid_fwd, kSmemFwdBytes)) return rc;
     if (split && (tiles < 1 || tiles > P8_TILES_MAX)) return fail(NDP_E_INVALID, "ndp_pyramid_fwd_batch_split_tiles: tiles per workgroup must be 1..8");
-    const int per_wg = NDP_TILE * (split ? tiles : NDP_PYR_TILES);                             // points per workgroup
+    const int per_wg = generic ? NDP_TILE : NDP_TILE * (split ? tiles : NDP_PYR_TILES);       // points per workgroup
     for (int j0 = 0; j0 < n_jobs; j0 += NDP_MAX_WARP_JOBS) {
         WarpJobs wj;
         memset(&wj, 0, sizeof wj);
@@ -2418,7 +2434,8 @@ static int pyramid_fwd_batch_impl(const ndp_layer_desc *desc, int m, int k0, int
             if (wgs > max_wgs) max_wgs = wgs;
         }
         if (!cnt) continue;
-        if (split) hipLaunchKernelGGL(k_pyramid_fwd8, dim3(max_wgs, cnt), dim3(512), kSmemPyr8Bytes, (hipStream_t)stream, *desc, m, k0, p_stride, wj, tiles);
+        if (generic) hipLaunchKernelGGL(k_gen_pyramid_fwd, dim3(max_wgs, cnt), dim3(256), gen_fwd_floats(desc->width) * 4, (hipStream_t)stream, *desc, m, k0, p_stride, wj);
+        else if (split) hipLaunchKernelGGL(k_pyramid_fwd8, dim3(max_wgs, cnt), dim3(512), kSmemPyr8Bytes, (hipStream_t)stream, *desc, m, k0, p_stride, wj, tiles);
         else hipLaunchKernelGGL(k_pyramid_fwd, dim3(max_wgs, cnt), dim3(256), kSmemFwdBytes, (hipStream_t)stream, *desc, m, k0, p_stride, wj);
         HIP_TRY(hipGetLastError(), "k_pyramid_fwd launch");
     }
@@ -2638,7 +2655,13 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     const dim3 g_fwd8(engine_g8(e), e->B);
     if (e->gemm_mode < 0 || e->gemm_mode > 511) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1), 64 (the Adam step inside the fused backward)");
     // both backward layers on the splits: ONE launch (k_eng_bwd_f, stage 3; stage 4 launches nothing) unless bit 16 asks for the two round-3 kernels
-    const bool bwd_fused = (e->gemm_mode & 7) == 7 && !(e->gemm_mode & 16);   // (it reads h1 as the SPLIT forward's plane image: without bit 1 the two launches run)
+    // width / depth other than 128 / 3: the generic fp32 level kernels (csrc/ndp_generic.inc); gemm_mode selects nothing there
+    const bool generic = gen_is_generic(e->desc);
+    if (generic) {
+        if (int rc = set_smem((const void *)k_eng_fwd_gen, kSmemGenFwdMax)) return rc;
+        if (int rc = set_smem((const void *)k_eng_bwd_gen, kSmemGenBwdMax)) return rc;
+    }
+    const bool bwd_fused = !generic && (e->gemm_mode & 7) == 7 && !(e->gemm_mode & 16);   // (it reads h1 as the SPLIT forward's plane image: without bit 1 the two launches run)
     if (bwd_fused) if (int rc = set_smem((const void *)k_eng_bwd_f, kSmemBwdFBytes)) return rc;
     if (e->gemm_mode & 1) if (int rc = set_smem((const void *)k_eng_fwd8, kSmemFwd8Bytes)) return rc;
     if (e->gemm_mode & 2) if (int rc = set_smem((const void *)k_eng_bwd1_8, kSmemBwd18Bytes)) return rc;
@@ -2690,6 +2713,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
 #define NDP_ST(i) ((i) >= stage_lo && (i) <= stage_hi)
         NDP_EV();
         if (!NDP_ST(0)) {}
+        else if (generic) hipLaunchKernelGGL(k_eng_fwd_gen, g_lvl, blk, gen_fwd_floats(e->desc.width) * 4, s, *e, parity);
         else if (e->gemm_mode & 1) {
             hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity, warp_in_fwd ? 1 : 0);
             if (!warp_in_fwd) hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
@@ -2706,11 +2730,12 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         if (NDP_ST(2)) hipLaunchKernelGGL(k_eng_loss, g_loss, blk, 0, s, *e, parity);
         NDP_EV();
         if (!NDP_ST(3)) {}
+        else if (generic) hipLaunchKernelGGL(k_eng_bwd_gen, g_lvl, blk, gen_bwd_floats(e->desc.width) * 4, s, *e, parity);
         else if (bwd_fused) hipLaunchKernelGGL(k_eng_bwd_f, g_fwd8, dim3(512), kSmemBwdFBytes, s, *e, parity);
         else if (e->gemm_mode & 4) hipLaunchKernelGGL(k_eng_bwd2_8, g_fwd8, dim3(512), kSmemBwd8Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd2, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV();
-        if (!NDP_ST(4) || bwd_fused) {}
+        if (!NDP_ST(4) || bwd_fused || generic) {}
         else if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd18Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV();

@@ -113,7 +113,9 @@ class BatchedEngine:
         tiles = self.n_cap // N.TILE
         # workgroups per pair in the level kernels: two 4-wave workgroups per CU (fp32 kernels) or, when all three level kernels run
         # on fp16 splits, one 8-wave workgroup per CU -- then also half as many gradient partials to write and to fold
-        per_cu = 1 if (self.gemm_mode & 7) == 7 else 2
+        # (width / depth other than 128 / 3: the generic fp32 kernels, 4-wave workgroups; gemm_mode selects nothing there)
+        self.generic = desc.width != 128 or desc.n_hidden != 2
+        per_cu = 1 if (self.gemm_mode & 7) == 7 and not self.generic else 2
         self.G = int(G) if G else max(1, min(tiles, -(-256 * per_cu // B)))
         d = self.device
         f32 = dict(device=d, dtype=torch.float32)
@@ -125,7 +127,7 @@ class BatchedEngine:
         self.gpart = torch.zeros(B, self.G, self.p_stride, **f32)
         self.adam_m = torch.zeros(B, self.p_stride, **f32)
         self.adam_v = torch.zeros(B, self.p_stride, **f32)
-        self.act = torch.zeros(B, 3, self.n_cap, 128, **f32)
+        self.act = torch.zeros(B, desc.n_hidden + 1, self.n_cap, desc.width, **f32)    # [B, 3, n_cap, 128] for the shipped 128 / 3
         self.heads = torch.zeros(B, self.n_cap, N.HROW, **f32)
         self.dO = torch.zeros(B, self.n_cap, N.NHMAX, **f32)
         self.d2x = torch.zeros(B, self.n_cap, **f32)

@@ -35,15 +35,16 @@ def cap(n):
 
 
 def level_fwd(desc: LayerDesc, params, level, k0, x, save=False, want_nonrig=False):
-    """x [n,3] -> x_out [n,3]; with save also (act [3,cap,128], heads [cap,24]); with want_nonrig the gate
-    values [n] of a level that carries the nonrigidity head are appended."""
+    """x [n,3] -> x_out [n,3]; with save also (act [depth,cap,width], heads [cap,24]; [3,cap,128] for the shipped 128 / 3); with
+    want_nonrig the gate values [n] of a level that carries the nonrigidity head are appended.  width / depth other than 128 / 3 run on
+    the generic fp32 kernels (csrc/ndp_generic.inc), bitwise the oracle's chain."""
     _chk(params, "params"); _chk(x, "x")
     n = x.shape[0]
     out = torch.empty_like(x)
     act = heads = nr = None
     if save:
         c = cap(n)
-        act = torch.empty(3, c, 128, device=x.device, dtype=torch.float32)
+        act = torch.empty(desc.n_hidden + 1, c, desc.width, device=x.device, dtype=torch.float32)
         heads = torch.empty(c, N.HROW, device=x.device, dtype=torch.float32)
     if want_nonrig and desc.nonrigidity:
         nr = torch.empty(n, device=x.device, dtype=torch.float32)
@@ -62,6 +63,8 @@ def level_bwd(desc: LayerDesc, params, level, k0, x, act, heads, g, n_part=None,
     if g_nr is not None:
         _chk(g_nr, "g_nr")
     n = x.shape[0]
+    if tuple(act.shape) != (desc.n_hidden + 1, cap(n), desc.width) or tuple(heads.shape) != (cap(n), N.HROW):
+        raise N.NdpError(f"level_bwd: act must be [{desc.n_hidden + 1}, {cap(n)}, {desc.width}] and heads [{cap(n)}, {N.HROW}] as level_fwd(save=True) left them")
     P = desc.param_count
     stride = (P + 3) // 4 * 4
     tiles = (n + TILE - 1) // TILE

@@ -559,8 +559,8 @@ class Registration:
             if ls.ndim != 2 or ls.shape[1] != 3 or tuple(ls.shape) != tuple(lt.shape) or ls.shape[0] < 1:
                 raise ValueError(f"landmarks must be two [K, 3] tensors with the same K >= 1, got {tuple(ls.shape)} and {tuple(lt.shape)}")
         dev = self._dev()
-        if c.depth != 3 or c.width != 128:
-            raise N.NdpError("the HIP kernels are specialised for depth=3, width=128 (NDP.yaml / LNDP.yaml)")
+        if not (1 <= c.width <= 256 and 1 <= c.depth <= 4):        # (128 / 3: the MFMA kernels; the rest: csrc/ndp_generic.inc)
+            raise N.NdpError(f"width must be 1..256 and depth 1..4, got width={c.width}, depth={c.depth}")
         p = _Prepared()
         # registration.py:133-140 -- all m levels are initialised up front on the CPU generator
         p.desc, descs = self._pair_descs()                                          # engine: "levels > 0 gated"

@@ -72,3 +72,18 @@ def engine_modes(arith, n_cap=None, nn_mode=None):
 def registration_modes(arith):
     """Registration keyword arguments of an arithmetic configuration."""
     return dict(gemm_mode=7, nn_matrix=True) if arith == "split" else dict(gemm_mode=0, nn_matrix=False)
+
+
+# width / depth other than the shipped 128 / 3 (fixture F16, tests/golden/make_golden.py: F16_SHAPES)
+GENERIC_SHAPES = {
+    "w64d2_se3aa": dict(width=64, depth=2, rotation_format="axis_angle", motion="SE3"),
+    "w256d4_sim3eu": dict(width=256, depth=4, rotation_format="euler", motion="Sim3"),
+    "w32d1_sflow": dict(width=32, depth=1, rotation_format="axis_angle", motion="sflow"),
+    "w100d3_se3quat_nr": dict(width=100, depth=3, rotation_format="quaternion", motion="SE3", nonrigidity_est=True),
+}
+
+
+def generic_pyramid(seed, tag=None, m=5, device="cpu", **kw):
+    torch.manual_seed(seed)
+    kw = dict(GENERIC_SHAPES[tag], **kw) if tag else kw
+    return Deformation_Pyramid(device=device, k0=-8, m=m, **kw)

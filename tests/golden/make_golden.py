@@ -960,6 +960,69 @@ def F15_embedded_deformation(reg_mod, loss_mod, EasyDict, **_):
     save("F15_embedded_deformation", **out)
 
 
+# width / depth other than the shipped 128 / 3 (model/nets.py:65-110,295-304 build whatever the YAML names): the seeded initialisation,
+# one level's forward + gradients, the whole pyramid, and a short traced register() -- for the generic kernels (csrc/ndp_generic.inc)
+F16_SHAPES = {
+    "w64d2_se3aa": dict(width=64, depth=2, rotation_format="axis_angle", motion="SE3"),
+    "w256d4_sim3eu": dict(width=256, depth=4, rotation_format="euler", motion="Sim3"),
+    "w32d1_sflow": dict(width=32, depth=1, rotation_format="axis_angle", motion="sflow"),
+    "w100d3_se3quat_nr": dict(width=100, depth=3, rotation_format="quaternion", motion="SE3", nonrigidity_est=True),
+}
+
+
+def F16_generic_width(nets, reg_mod, loss_mod, EasyDict, **_):
+    out = {}
+    g = torch.Generator().manual_seed(16)
+    x = torch.rand(200, 3, generator=g) - 0.5
+    coef = torch.linspace(-1.0, 1.0, 200 * 3).reshape(200, 3)
+    out["x"] = x.numpy()
+    out["head_scale"] = np.float32(30.0)
+    out["seed"] = np.int64(16)
+    out["level"] = np.int64(3)
+    for tag, kw in F16_SHAPES.items():
+        torch.manual_seed(16)
+        pyr = nets.Deformation_Pyramid(device="cpu", k0=-8, m=5, **kw)
+        names, sums, asums, heads = [], [], [], []
+        for li, layer in enumerate(pyr.pyramid):
+            for k, v in layer.named_parameters():
+                a = v.detach().double().numpy().ravel()
+                names.append(f"{li}.{k}")
+                sums.append(a.sum())
+                asums.append(np.abs(a).sum())
+                h = np.zeros(8)
+                h[:min(8, a.size)] = a[:8]
+                heads.append(h)
+        out[f"{tag}.names"] = np.array(names)
+        out[f"{tag}.sum"] = np.array(sums)
+        out[f"{tag}.abssum"] = np.array(asums)
+        out[f"{tag}.head8"] = np.array(heads)
+        out[f"{tag}.perm4096"] = torch.randperm(4096)[:16].numpy()
+        layer = pyr.pyramid[3]
+        with torch.no_grad():
+            for k, v in layer.named_parameters():
+                if "branch" in k or "brach" in k:
+                    v.mul_(30.0)
+        y, data = pyr.warp(x, max_level=3, min_level=3)
+        out[f"{tag}.out"] = y.detach().numpy()
+        for p in layer.parameters():
+            p.grad = None
+        (y * coef).sum().backward()
+        for k, v in layer.named_parameters():
+            out[f"{tag}.grad.{k}"] = v.grad.numpy().copy()
+        with torch.no_grad():
+            yfull, _ = pyr.warp(x)
+        out[f"{tag}.full_out"] = yfull.numpy()
+    # a short register() at width 64 / depth 2 (NDP.yaml otherwise): loss trace, evaluations per level, warped points
+    src, tgt, flow_gt, overlap = synthetic_pair(6, n_total=2048)
+    cfg = ndp_config(EasyDict, samples=256, width=64, depth=2, m=5, iters=60)
+    warped, trace = _register_traced(reg_mod, EasyDict, cfg, src, tgt, seed=0)
+    out["reg.src"], out["reg.tgt"] = src.numpy(), tgt.numpy()
+    out["reg.warped"] = warped.numpy()
+    out["reg.iters_per_level"] = np.array([len(t) for t in trace])
+    out["reg.loss_trace"] = np.array(sum(trace, []), dtype=np.float64)
+    save("F16_generic_width", **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -977,7 +1040,7 @@ def main():
         "F7": F7_end_to_end, "F8": F8_metrics, "F9": F9_landmarks, "F9b": F9b_lndp_end_to_end,
         "F9c": F9c_mixed_landmark_chamfer,
         "F10": F10_benchmark, "F10b": F10b_surface_benchmark, "F10c": F10c_surface_benchmark_seeds, "F11": F11_nonrigidity, "F12": F12_nsfp,
-        "F13": F13_shape_transfer, "F14": F14_nerfies, "F15": F15_embedded_deformation,
+        "F13": F13_shape_transfer, "F14": F14_nerfies, "F15": F15_embedded_deformation, "F16": F16_generic_width,
     }
     only = [s for s in args.only.split(",") if s]
     for k, fn in todo.items():

@@ -65,16 +65,19 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     from deformationpyramid_amd import _native
     from deformationpyramid_amd.layout import LayerDesc
     L = _native.lib()
-    bad = LayerDesc(width=64).c_struct()
+    bad = LayerDesc(width=257).c_struct()                            # (1..256 x depth 1..4 are served since round 6: csrc/ndp_generic.inc)
     rc = L.ndp_level_fwd(ctypes.byref(bad), None, 0, -8, None, 0, None, None, None, None, None)
-    assert rc == -2 and b"width=128" in L.ndp_last_error()
+    assert rc == -2 and b"width must be 1..256" in L.ndp_last_error()
+    bad = LayerDesc(width=64, n_hidden=4).c_struct()
+    rc = L.ndp_level_fwd(ctypes.byref(bad), None, 0, -8, None, 0, None, None, None, None, None)
+    assert rc == -2 and b"depth 1..4" in L.ndp_last_error()
     ok = LayerDesc().c_struct()
     assert L.ndp_level_fwd(ctypes.byref(ok), None, 0, -8, None, 5, None, None, None, None, None) == -1
     assert L.ndp_chamfer_nn_fwd(None, 0, None, 0, None, None, None, None, None) == -1
     assert L.ndp_pair_means(None, 0, None, 0, None, None) == -1
     assert L.ndp_pyramid_fwd_batch(ctypes.byref(ok), 9, -8, 8, None, 1, None) == -1            # p_stride < P
     assert L.ndp_engine_load(None, 0, None, 0, None) == -1
-    deep = LayerDesc(n_hidden=3).c_struct()                     # depth 4: kernels are specialised for depth 3
+    deep = LayerDesc(n_hidden=4).c_struct()                     # depth 5: beyond what the generic kernels (and the oracle) carry
     assert L.ndp_level_fwd(ctypes.byref(deep), None, 0, -8, None, 0, None, None, None, None, None) == -2
     for fmt in ("axis_angle", "euler", "quaternion", "6D"):     # n = 0 is a valid no-op for every served variant
         for gate in (False, True):

@@ -419,3 +419,57 @@ def test_F11_oracle_level_loop_matches_hand_rolled_bce(golden):
     assert abs(r["loss_trace"][0] - float(O.chamfer(w0, g["it.y"])["loss"])) < 1e-7
     # at level 1 the BCE term is present (loss > Chamfer alone)
     assert r["loss_trace"][4] > 0.5 * 0.6                        # w_reg * -log(1 - 0.5) = 0.35 at init, plus Chamfer
+
+
+# ------------------------------------------------- F16: width / depth other than 128 / 3 (model/nets.py:65-110,295-304)
+from tests._helpers import GENERIC_SHAPES, generic_pyramid
+
+
+@pytest.mark.parametrize("tag", list(GENERIC_SHAPES))
+def test_F16_generic_width_init_forward_grads_and_pyramid(golden, tag):
+    """The init replay, the oracle's level forward / backward and its pyramid at other widths and depths, against the reference."""
+    g = golden("F16_generic_width")
+    pyr = generic_pyramid(int(g["seed"]), tag)
+    names, sums, asums, heads = [], [], [], []
+    for li, layer in enumerate(pyr.pyramid):
+        for k, v in layer.named_parameters():
+            a = v.detach().double().numpy().ravel()
+            names.append(f"{li}.{k}")
+            sums.append(a.sum())
+            asums.append(np.abs(a).sum())
+            h = np.zeros(8)
+            h[:min(8, a.size)] = a[:8]
+            heads.append(h)
+    assert names == list(g[f"{tag}.names"])
+    np.testing.assert_array_equal(np.array(heads), g[f"{tag}.head8"])          # bit-exact RNG replay at this width / depth
+    np.testing.assert_allclose(np.array(sums), g[f"{tag}.sum"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(np.array(asums), g[f"{tag}.abssum"], rtol=1e-12)
+    np.testing.assert_array_equal(torch.randperm(4096)[:16].numpy(), g[f"{tag}.perm4096"])
+    lvl, x = int(g["level"]), g["x"]
+    scale_heads(pyr, lvl, float(g["head_scale"]))
+    d = pyr.descs[lvl]
+    assert d.width == GENERIC_SHAPES[tag]["width"] and d.n_hidden == GENERIC_SHAPES[tag]["depth"] - 1
+    params = pyr.store[lvl, :d.param_count].numpy()
+    out = O.level_fwd(cdesc(d), params, lvl, K0, x)
+    np.testing.assert_allclose(out, g[f"{tag}.out"], rtol=0, atol=1e-5 if "quat" in tag else 2e-6)
+    coef = torch.linspace(-1.0, 1.0, x.shape[0] * 3).reshape(-1, 3).numpy()
+    grads = O.level_bwd(cdesc(d), params, lvl, K0, x, coef)
+    for name, off, shape in d.named_slices():
+        ref = g[f"{tag}.grad.{name}"]
+        got = grads[off:off + ref.size].reshape(ref.shape)
+        assert rel_err(got, ref) < 1e-4, (tag, name, rel_err(got, ref))
+    descs = [cdesc(dd) for dd in pyr.descs]
+    params_all = np.concatenate([pyr.store[i, :dd.param_count].numpy() for i, dd in enumerate(pyr.descs)])
+    full = O.pyramid_fwd(descs, K0, params_all, x)
+    np.testing.assert_allclose(full, g[f"{tag}.full_out"], rtol=0, atol=2e-5 if "quat" in tag else 5e-6)
+
+
+def test_F16_stop_rule_replays_the_reference_at_width_64(golden):
+    g = golden("F16_generic_width")
+    trace, counts = g["reg.loss_trace"], g["reg.iters_per_level"]
+    pos = 0
+    for c in counts:
+        brk, _, _ = O.stop_trace(trace[pos:pos + c])
+        assert brk == (c - 1 if c < 60 else c), (brk, c)
+        pos += c
+    assert pos == len(trace) and len(counts) == 5

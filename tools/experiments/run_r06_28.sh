@@ -1,0 +1,4 @@
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r06
+timeout 1500 python -m pytest tests/test_generic_width.py -q -m gpu > gpurun_out/r06/t_generic.txt 2>&1
+tail -40 gpurun_out/r06/t_generic.txt
