@@ -10,8 +10,11 @@
  * code it replaces; INTEGRATION.md shows the ctypes binding a maintainer would add.
  *
  * Parameter layout of one level: include/ndp_types.h.  Points are float32 [n][3] row-major.
- * The kernels are specialised for width = 128, depth = 3 (both shipped configs: NDP.yaml:24-25,
- * LNDP.yaml:45-46); other shapes return NDP_E_UNSUPPORTED.
+ * width = 128, depth = 3 (both shipped configs: NDP.yaml:24-25, LNDP.yaml:45-46) run on the MFMA kernels.  Every other
+ * 1 <= width <= 256, 1 <= depth <= 4 the YAML can name (the reference builds any: nets.py:75,295-304) runs behind the SAME
+ * entry points on generic fp32 kernels (csrc/ndp_generic.inc: the oracle's fmaf chains on the vector pipe, ~1/10 of the rate
+ * at 128 / 3; gemm_mode and the `split` entries select nothing there).  Their activation store is
+ * [depth][n_cap][width] fp32 rows wherever this header says [3][n_cap][128].  Shapes beyond return NDP_E_UNSUPPORTED.
  */
 #ifndef NDP_HIP_H
 #define NDP_HIP_H
@@ -41,7 +44,7 @@ int ndp_abi_sizes(int *out6);
 /* NDPLayer.forward for one level on n points (nets.py:111-140; posenc :164-177; MLP :295-304;
  * get_Rotation :144-161; rigid_body.py:19-56,89-119).
  *   x [n][3] -> x_out [n][3].
- *   act  (may be NULL): [3][n_cap][128] saved post-ReLU activations h0,h1,h2 for ndp_level_bwd
+ *   act  (may be NULL): [3][n_cap][128] saved post-ReLU activations h0,h1,h2 for ndp_level_bwd ([depth][n_cap][width] in general)
  *   heads(may be NULL): [n_cap][NDP_HROW] per-point record: 16 scaled head outputs (rot.., scale,
  *                       trn, nr) followed by the 6 positional-encoding values and 2 pad floats
  *   nonrig_out (may be NULL): [n] gate values sigmoid(0.001 nr_branch(h)) when desc->nonrigidity
@@ -53,7 +56,7 @@ int ndp_level_fwd(const ndp_layer_desc *desc, const float *params, int level, in
 
 /* Backward of one level wrt its parameters given g = dL/dx_out [n][3] (autograd of nets.py:111-140;
  * x is a detached input, registration.py:243-249).  act/heads come from ndp_level_fwd on the same
- * x and params; act is CONSUMED (its h2 plane is overwritten with an intermediate).  dO_work is
+ * x and params; act is CONSUMED at 128 / 3 (its h2 plane is overwritten with an intermediate; the generic kernels leave it).  dO_work is
  * scratch of [n_cap][16] floats; g_nr (may be NULL) = dL/d(gate) [n] when desc->nonrigidity.  grads_part [n_part][P_stride] receives n_part partial sums
  * (deterministic: workgroup g sums tiles g, g+n_part, ...); ndp_grad_reduce folds them in index order. */
 int ndp_level_bwd(const ndp_layer_desc *desc, const float *params, int level, int k0,
@@ -247,7 +250,7 @@ typedef struct ndp_engine {
     float *params;                   /* [B][m][p_stride]                                        */
     float *gpart;                    /* [B][G][p_stride]                                        */
     float *adam_m, *adam_v;          /* [B][p_stride]                                           */
-    float *act;                      /* [B][3][n_cap][128] fp32 rows of h0, h1, h2 -- except under the default gemm_mode 7 (fused
+    float *act;                      /* [B][3][n_cap][128] fp32 rows of h0, h1, h2 ([B][depth][n_cap][width] for other shapes) -- except under the default gemm_mode 7 (fused
                                         split backward), where planes 1 and 2 hold h1 and (since ABI 202) h2 per 64-point tile as a
                                         PLANE IMAGE of the same size: two [64][128] fp16 planes hi = fp16(2^6 h) | lo = fp16(2^6 h - hi),
                                         rows of 256 bytes with their 16-byte granules XOR-swizzled (csrc/ndp_fwd_split.inc: bf_swz) --
