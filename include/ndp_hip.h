@@ -12,8 +12,8 @@
  * Parameter layout of one level: include/ndp_types.h.  Points are float32 [n][3] row-major.
  * width = 128, depth = 3 (both shipped configs: NDP.yaml:24-25, LNDP.yaml:45-46) run on the MFMA kernels.  Every other
  * 1 <= width <= 256, 1 <= depth <= 4 the YAML can name (the reference builds any: nets.py:75,295-304) runs behind the SAME
- * entry points on generic fp32 kernels (csrc/ndp_generic.inc: the oracle's fmaf chains on the vector pipe, ~1/10 of the rate
- * at 128 / 3; gemm_mode and the `split` entries select nothing there).  Their activation store is
+ * entry points on generic fp32 kernels (csrc/ndp_generic.inc: the oracle's chains on the fp32 matrix instruction, about a third
+ * of the 128 / 3 kernels' rate per layer; gemm_mode and the `split` entries select nothing there).  Their activation store is
  * [depth][n_cap][width] fp32 rows wherever this header says [3][n_cap][128].  Shapes beyond return NDP_E_UNSUPPORTED.
  */
 #ifndef NDP_HIP_H

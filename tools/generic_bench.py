@@ -1,6 +1,6 @@
 """Throughput of the generic level kernels (csrc/ndp_generic.inc) next to the MFMA kernels of the shipped 128 / 3:
 whole register_batch() jobs of synthetic 8192-pt pairs (NDP.yaml otherwise) at several width / depth, pairs/s and ms per tick.
-    python tools/generic_bench.py [pairs] [slots]"""
+    python tools/generic_bench.py [pairs] [slots] [WxD ...]       (e.g. 128x2 256x4; default: a table of eight shapes)"""
 import os, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,7 +14,8 @@ slots = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 dev = torch.device("cuda:0")
 base = load_config(os.path.join(ROOT, "config", "NDP.yaml"), device=0)
 pairs = [tuple(t.to(dev) for t in synthetic_pair(i)[:2]) for i in range(n_pairs)]
-for width, depth in ((128, 3), (64, 2), (64, 3), (128, 2), (128, 4), (256, 3), (256, 4), (32, 1)):
+shapes = [tuple(int(v) for v in a.split("x")) for a in sys.argv[3:]] or [(128, 3), (64, 2), (64, 3), (128, 2), (128, 4), (256, 3), (256, 4), (32, 1)]
+for width, depth in shapes:
     cfg = Config(base, width=width, depth=depth)
     model = Registration(cfg)
     torch.manual_seed(0)
