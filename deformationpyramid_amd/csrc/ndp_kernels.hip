@@ -1592,10 +1592,19 @@ __device__ __forceinline__ float block_sum_256_t(float v, float *scratch, int t,
     if (act) scratch[t] = v;
     __syncthreads();
 #pragma unroll
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = 128; s >= 64; s >>= 1) {
         if (act && t < s) scratch[t] = scratch[t] + scratch[t + s];
         __syncthreads();
     }
+    // the tree's last six levels live in one wave: lane shuffles instead of LDS + a barrier per level (lane t < s adds the value of lane
+    // t + s exactly as scratch[t] + scratch[t + s] did: the same association, the same bits)
+    if (act && t < 64) {
+        float x = scratch[t];
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) x = x + __shfl_down(x, s);
+        if (t == 0) scratch[0] = x;
+    }
+    __syncthreads();
     const float r = scratch[0];
     __syncthreads();
     return r;
@@ -1812,19 +1821,21 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
                 if (li[k] >= 0 && li[k] < 256) atomicAdd(&cnt[li[k]], 1);
             __syncthreads();
             PT(1);
-            // exclusive scan of cnt -> start (Hillis-Steele over 256 entries)
+            // exclusive scan of cnt -> start: inclusive scan inside each wave by lane shuffles, the four wave totals through LDS (two
+            // barriers; until round 6 a Hillis-Steele scan through LDS with sixteen of them -- integers: the same offsets)
             const int mine = cnt[t];
-            if (act) start[t] = mine;
-            __syncthreads();
+            int inc = mine;
 #pragma unroll
-            for (int d = 1; d < 256; d <<= 1) {
-                const int v = t >= d ? start[t - d] : 0;
-                __syncthreads();
-                if (act) start[t] += v;
-                __syncthreads();
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(inc, d);
+                if ((t & 63) >= d) inc += v;
             }
-            const int my_start = start[t] - mine;
+            int *wsum = reinterpret_cast<int *>(red);                     // (the gradient workgroups have no other use for `red`)
+            if (act && (t & 63) == 63) wsum[t >> 6] = inc;
             __syncthreads();
+            int my_start = inc - mine;
+#pragma unroll
+            for (int w2 = 0; w2 < 3; ++w2) my_start += w2 < (t >> 6) ? wsum[w2] : 0;
             if (act) start[t] = my_start;                                 // becomes the fill cursor
             if (c0 == 0) LOSS_HR_STORE();
             __syncthreads();

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06
-timeout 2400 python -m pytest tests -x -q -m gpu > gpurun_out/r06/t_all3.txt 2>&1
-tail -4 gpurun_out/r06/t_all3.txt
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-python tools/tick_bench.py 256 24 2>&1 | tail -1
+NDP_TICK_HASH=1 bash tools/experiments/ab.sh "s0 s1" 3 256 24 > gpurun_out/r06/ab_stage.txt 2>&1
+NDP_TICK_HASH=1 bash tools/experiments/ab.sh "s0 s1" 2 128 24 >> gpurun_out/r06/ab_stage.txt 2>&1
+NDP_TICK_HASH=1 bash tools/experiments/ab.sh "s0 s1" 2 1 96 >> gpurun_out/r06/ab_stage.txt 2>&1
+cat gpurun_out/r06/ab_stage.txt | cut -c1-220
