@@ -1611,9 +1611,13 @@ __device__ __forceinline__ float block_sum_256_t(float v, float *scratch, int t,
 }
 __device__ __forceinline__ float l1_sum_t(const float *d2, int n, float trunc, float *scratch, int t, bool act) {
     float s = 0.f;
-    for (int i = act ? t : n; i < n; i += 256) {
-        const float v = d2[i];
-        s += (v >= trunc) ? 0.f : sqrtf(v);
+    for (int i0 = act ? t : n; i0 < n; i0 += 8 * 256) {             // eight values requested together, added in index order (one global round
+        float v[8];                                                 // trip per 2048 entries instead of eight: round 6)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = i0 + 256 * u < n ? d2[i0 + 256 * u] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + 256 * u < n) s += (v[u] >= trunc) ? 0.f : sqrtf(v[u]);
     }
     return block_sum_256_t(s, scratch, t, act);
 }
@@ -1761,11 +1765,19 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
     // chunk's nearest-source indices (local point of target c0 + t + 256 k, -1: not ours) travel with the row partials.
     const bool scatter = use_cd && vb * 256 + 255 >= gm.K;      // workgroup holds at least one sample
     const int i_lo = vb * 256 - gm.K;                      // sample index of thread 0
+    // (UNCONDITIONAL loads at a clamped index -- idx_y is padded with -1 up to t_cap: as `cond ? idx_y[j] : -1` every one of the eight
+    //  became a branch around a load with its own wait, eight dependent global round trips at the top of every gradient workgroup,
+    //  a third of its time: round 6)
     int li[LG_CHUNK / 256];
 #pragma unroll
-    for (int k = 0; k < LG_CHUNK / 256; ++k) {
-        const int j = t + 256 * k;
-        li[k] = scatter && act && j < gm.T ? idx_y[j] - i_lo : -1;
+    for (int k = 0; k < LG_CHUNK / 256; ++k) li[k] = -1;
+    if (scatter) {
+        const int jcap = e.t_cap - 1;
+        int raw[LG_CHUNK / 256];
+#pragma unroll
+        for (int k = 0; k < LG_CHUNK / 256; ++k) raw[k] = idx_y[min(t + 256 * k, jcap)];
+#pragma unroll
+        for (int k = 0; k < LG_CHUNK / 256; ++k) li[k] = act && t + 256 * k < gm.T ? raw[k] - i_lo : -1;
     }
     if (p < gm.K) {
         const float invK = 1.0f / (float)gm.K;
@@ -1809,7 +1821,8 @@ __device__ __forceinline__ void eng_loss_body(const ndp_engine &e, int parity, i
 #pragma unroll
                 for (int k = 0; k < LG_CHUNK / 256; ++k) {
                     const int j = t + 256 * k;
-                    li[k] = act && j < cn ? idx_y[c0 + j] - i_lo : -1;
+                    const int raw = idx_y[min(c0 + j, e.t_cap - 1)];
+                    li[k] = act && j < cn ? raw - i_lo : -1;
                 }
             }
             __syncthreads();

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06
-bash tools/experiments/sweep3.sh "3:256:4 2:256:4 4:256:4 3:256:8 3:256:2 3:256:4 2:256:4 4:256:4 3:256:8 3:256:2" 8 > gpurun_out/r06/engines_sweep_long.txt 2>&1
-cat gpurun_out/r06/engines_sweep_long.txt
+NDP_TICK_HASH=1 bash tools/experiments/ab.sh "s2 s3 s4" 3 256 24 > gpurun_out/r06/ab_nn_prologue.txt 2>&1
+NDP_TICK_HASH=1 bash tools/experiments/ab.sh "s2 s3 s4" 2 128 24 >> gpurun_out/r06/ab_nn_prologue.txt 2>&1
+cat gpurun_out/r06/ab_nn_prologue.txt | cut -c1-220
