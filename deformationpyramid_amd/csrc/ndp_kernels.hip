@@ -1037,8 +1037,13 @@ __device__ __forceinline__ void nn_lat_body(const float *q, int nq, const float 
     float *cb = sm + 3 * NN_STAGE;
     int *ci = reinterpret_cast<int *>(cb + NT);
     const int i = qbase + lane;
-    float qc[3] = {0.f, 0.f, 0.f};
-    if (i < nq) { qc[0] = q[3 * (size_t)i]; qc[1] = q[3 * (size_t)i + 1]; qc[2] = q[3 * (size_t)i + 2]; }
+    // (the query is requested unconditionally at a clamped index, next to the stage's references: behind `if (i < nq)` it was a global
+    //  round trip of its own in front of them; a lane beyond nq scans with the last query and writes nothing)
+    float qc[3];
+    {
+        const float *qp = q + 3 * (size_t)min(i, nq - 1);
+        qc[0] = qp[0]; qc[1] = qp[1]; qc[2] = qp[2];
+    }
     const f32x2 qx = {qc[0], qc[0]}, qy = {qc[1], qc[1]}, qz = {qc[2], qc[2]};
     float best = INFINITY;
     int sc_best = -1;
@@ -1079,13 +1084,29 @@ __device__ __forceinline__ void nn_lat_body(const float *q, int nq, const float 
             if (m < best) { best = m; sc_best = c0 / NN_SUB + sc; }
         }
     }
+    // Which reference of the winning sub-chunk: its NN_SUB candidates are requested TOGETHER -- from the LDS stage when there was only
+    // one (the references are still there: the same values), from global memory at a clamped index otherwise -- and compared from the
+    // last to the first (the lowest index of the minimum stays).  Until round 6 a loop of one global round trip per candidate: sixteen
+    // dependent round trips, a third of the batch-1 stage.
     int bi = -1;
     if (sc_best >= 0 && i < nq) {
-        const int j0 = sc_best * NN_SUB, j1 = min(j0 + NN_SUB, nr);
-        for (int j = j1 - 1; j >= j0; --j) {
-            const float dx = qc[0] - r[3 * (size_t)j], dy = qc[1] - r[3 * (size_t)j + 1], dz = qc[2] - r[3 * (size_t)j + 2];
+        const int j0 = sc_best * NN_SUB;
+        float rx[NN_SUB], ry[NN_SUB], rz[NN_SUB];
+        if (nr <= NN_STAGE) {
+#pragma unroll
+            for (int u = 0; u < NN_SUB; ++u) { rx[u] = xs[j0 + u]; ry[u] = ys[j0 + u]; rz[u] = zs[j0 + u]; }   // (NaN beyond nr: never equal)
+        } else {
+#pragma unroll
+            for (int u = 0; u < NN_SUB; ++u) {
+                const float *rp = r + 3 * (size_t)min(j0 + u, nr - 1);
+                rx[u] = rp[0]; ry[u] = rp[1]; rz[u] = rp[2];
+            }
+        }
+#pragma unroll
+        for (int u = NN_SUB - 1; u >= 0; --u) {
+            const float dx = qc[0] - rx[u], dy = qc[1] - ry[u], dz = qc[2] - rz[u];
             const float dd = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-            if (dd == best) bi = j;
+            if (j0 + u < nr && dd == best) bi = j0 + u;
         }
     }
     // The quarters of one stage are in reference order, but a later stage's quarter w precedes nothing of an earlier
@@ -1495,10 +1516,12 @@ __device__ __forceinline__ void nn1_body(const float *xs, int S, const float *ys
 template <int NW>
 __device__ __forceinline__ void eng_nn_lat_stage(const ndp_engine &e, int parity, float *sm) {
     const int b = blockIdx.y;
-    const ndp_pair_state st = e.state[parity * e.B + b];
-    if (st.level >= e.m) return;
+    // (level, buffer parity and geometry requested side by side, ONE test: see eng_nn_mx_body)
+    const ndp_pair_state *stp = e.state + (size_t)parity * e.B + b;
+    struct { int level, cur; } st;
+    st.level = stp->level; st.cur = stp->cur;
     const ndp_pair_geom gm = e.geom[b];
-    if (gm.S == 0 || e.w_cd == 0.f) return;
+    if ((st.level >= e.m) | (gm.S == 0) | (st.cur < 0) | (e.w_cd == 0.f)) return;
     const float *xw = e.pts + ((size_t)b * 2 + (st.cur ^ 1)) * e.n_cap * 3 + 3 * gm.K;
     const float *y = e.tgt + (size_t)b * e.t_cap * 3;
     const int bx = e.n_cap / 64;
@@ -1990,18 +2013,32 @@ __device__ __forceinline__ void eng_update_param(const ndp_engine &e, int b, con
     }
     if (ns.decision != NDP_DEC_ADVANCE) {
         const float *gp = e.gpart + (size_t)b * e.G * e.p_stride;
+        float *p = e.params + ((size_t)b * e.m + ns.step_level) * e.p_stride;
+        float pi = p[i], mi = m[i], vi = v[i];                           // (requested with the partials, not behind their fold)
         float g = __builtin_nontemporal_load(gp + i);
         int k = 1;
-        for (; k + 8 <= e.G; k += 8) {                               // eight partials requested together, added in index order (batch 1 folds 32)
-            float q[8];
+        // The other partials are requested TOGETHER (clamped index, added in index order while k < G): batch 1 folds G = 32 of them, and as
+        // three batches of eight plus a tail of seven single loads that was eleven dependent global round trips (round 6).
+        if (e.G > 9) {
+            for (; k < e.G; k += 32) {
+                float q[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) q[u] = gp[(size_t)(k + u) * e.p_stride + i];
+                for (int u = 0; u < 32; ++u) q[u] = gp[(size_t)min(k + u, e.G - 1) * e.p_stride + i];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) g += q[u];
+                for (int u = 0; u < 32; ++u)
+                    if (k + u < e.G) g += q[u];
+            }
+        } else if (e.G > 3) {
+            for (; k < e.G; k += 8) {
+                float q[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) q[u] = gp[(size_t)min(k + u, e.G - 1) * e.p_stride + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (k + u < e.G) g += q[u];
+            }
         }
         for (; k < e.G; ++k) g += gp[(size_t)k * e.p_stride + i];
-        float *p = e.params + ((size_t)b * e.m + ns.step_level) * e.p_stride;
-        float pi = p[i], mi = m[i], vi = v[i];
         adam_update(pi, g, mi, vi, e.adam_w1, e.adam_b2, e.adam_w2, e.adam_tab[2 * ns.step_t],
                     e.adam_tab[2 * ns.step_t + 1], e.adam_eps);
         p[i] = pi; m[i] = mi; v[i] = vi;
@@ -2011,10 +2048,13 @@ __device__ __forceinline__ void eng_update_param(const ndp_engine &e, int b, con
 extern "C" __global__ void __launch_bounds__(256)
 k_eng_update(ndp_engine e, int parity) {
     const int b = blockIdx.y;
-    const ndp_pair_state ns = e.state[(size_t)(parity ^ 1) * e.B + b];      // written by k_eng_loss this tick
-    if (ns.decision == NDP_DEC_IDLE) return;
+    // (the three fields the step needs, requested side by side and tested once: behind the test on the decision the level and the step
+    //  number were a second dependent scalar round trip)
+    const ndp_pair_state *nsp = e.state + (size_t)(parity ^ 1) * e.B + b;   // written by k_eng_loss this tick
+    ndp_pair_state ns;
+    ns.decision = nsp->decision; ns.step_level = nsp->step_level; ns.step_t = nsp->step_t;
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= e.P) return;
+    if ((ns.decision == NDP_DEC_IDLE) | (i >= e.P) | (ns.step_level < 0) | (ns.step_t < 0)) return;
     eng_update_param(e, b, ns, desc_at_level(e.desc, ns.step_level), i);
 }
 
