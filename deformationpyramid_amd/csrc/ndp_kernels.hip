@@ -1548,6 +1548,13 @@ k_eng_nn_lat8(ndp_engine e, int parity) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     eng_nn_lat_stage<8>(e, parity, sm);
 }
+// sixteen waves per 64 queries (each scans a sixteenth of every stage): the engine's launch since round 6 when the pair count is small
+// enough for the stage to be ONE workgroup's latency (B <= 2: the scan of a stage is half as long; same fold, same results)
+extern "C" __global__ void __launch_bounds__(1024)
+k_eng_nn_lat16(ndp_engine e, int parity) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    eng_nn_lat_stage<16>(e, parity, sm);
+}
 
 extern "C" __global__ void __launch_bounds__(256)
 k_eng_nn(ndp_engine e, int parity, int stage_x) {
@@ -2785,6 +2792,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         else hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         NDP_EV();
         if (!NDP_ST(1)) {}
+        else if (nn && e->nn_mode == 1 && !(e->gemm_mode & 128) && e->B <= 2) hipLaunchKernelGGL(k_eng_nn_lat16, g_nn_lat, dim3(1024), (3 * NN_STAGE + 2 * 1024) * 4, s, *e, parity);
         else if (nn && e->nn_mode == 1 && !(e->gemm_mode & 128)) hipLaunchKernelGGL(k_eng_nn_lat8, g_nn_lat, dim3(512), (3 * NN_STAGE + 2 * 512) * 4, s, *e, parity);
         else if (nn && e->nn_mode == 1) hipLaunchKernelGGL(k_eng_nn_lat, g_nn_lat, blk, kSmemNnLatBytes, s, *e, parity);
         else if (nn_mx8) hipLaunchKernelGGL(k_eng_nn_mx8, dim3((e->t_cap + 511) / 512, e->B), dim3(512), nn2_lds_floats(e->n_cap, 8) * 4, s, *e, parity);
