@@ -355,6 +355,22 @@ def test_engine_is_deterministic_and_G_independent_in_loss(dev, arith):
     assert abs(s1[0].loss - s3[0].loss) < 1e-5 * abs(s1[0].loss)
 
 
+@pytest.mark.parametrize("G", [3, 4, 9, 10, 16, 32, 33])
+def test_update_folds_any_number_of_partials(dev, G):
+    """The update kernel requests the G gradient partials in batches (<= 3: one by one, 4..9: eight at a clamped index, >= 10: 32 at a
+    clamped index, more than 33 in two batches) and adds them in index order: every branch against the oracle -- parameters after 2 x 4 Adam
+    steps and the warped points (north_star: 1e-4) -- on a pair with fewer tiles than workgroups (idle partials are zero)."""
+    eng, states, refs = _engine_vs_oracle(dev, "se3aa", K=0, S=700, T=650, m=2, iters=4, early_stop=False, w_cd=1.0, trunc=1e9, B=2, G=G,
+                                          arith="split")
+    P = eng.P
+    for b, (st, ref) in enumerate(zip(states, refs)):
+        assert st.level == 2 and st.total_steps == 8
+        assert abs(st.loss - ref["loss_trace"][-1]) < 1e-4 * abs(ref["loss_trace"][-1])
+        diff = np.abs(eng.params[b, :, :P].cpu().numpy().reshape(-1) - ref["params_all"])
+        assert np.mean(diff < 1e-4) > 0.97, np.mean(diff < 1e-4)
+        assert np.abs(eng.final_points(b, st).cpu().numpy() - ref["pts"]).max() < 1e-4
+
+
 # ------------------------------------------------------------------- nonrigidity gate + BCE (w_reg > 0)
 @pytest.mark.parametrize("tag", ["se3aa", "sim3quat", "sflow"])
 def test_gate_forward_backward_matches_oracle_and_reference(dev, golden, tag):
