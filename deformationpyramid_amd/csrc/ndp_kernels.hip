@@ -2747,6 +2747,12 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     // than six kernel boundaries.  Needs: fused split backward, latency-shape NN, one tile per workgroup, every workgroup resident.
     // one tile per level-kernel workgroup and few of them: the per-point warp rides in the forward launch (ndp_fwd_split.inc)
     const bool warp_in_fwd = (e->gemm_mode & 1) && (int)g_fwd8.x == e->n_cap / NDP_TILE && e->B * (int)g_fwd8.x <= 256;
+    // everything else on the split forward: the workgroup warps its tiles' points behind its tile loop (eng_warp_tail); bit 512 of
+    // gemm_mode keeps the separate k_eng_warp launch (A/B, tests)
+#ifndef NDP_WARP_TAIL
+#define NDP_WARP_TAIL 1
+#endif
+    const bool warp_tail = NDP_WARP_TAIL && (e->gemm_mode & 1) && !warp_in_fwd && !(e->gemm_mode & 512);
     const bool persistent = !ev && stage_lo == 0 && stage_hi == NDP_TICK_KERNELS - 1 && bwd_fused && (e->gemm_mode & 1) &&
                             (e->gemm_mode & 256) && !(e->gemm_mode & (32 | 64)) && (!nn || e->nn_mode == 1) && e->G == e->n_cap / NDP_TILE &&
                             e->B * e->G <= 256 && n_ticks > 0;
@@ -2786,8 +2792,8 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         if (!NDP_ST(0)) {}
         else if (generic) hipLaunchKernelGGL(k_eng_fwd_gen, g_lvl, blk, gen_fwd_floats(e->desc.width) * 4, s, *e, parity);
         else if (e->gemm_mode & 1) {
-            hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity, warp_in_fwd ? 1 : 0);
-            if (!warp_in_fwd) hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
+            hipLaunchKernelGGL(k_eng_fwd8, g_fwd8, dim3(512), kSmemFwd8Bytes, s, *e, parity, warp_in_fwd ? 1 : (warp_tail ? 2 : 0));
+            if (!warp_in_fwd && !warp_tail) hipLaunchKernelGGL(k_eng_warp, dim3((e->n_cap + 255) / 256, e->B), blk, 0, s, *e, parity);
         }
         else hipLaunchKernelGGL(k_eng_fwd, g_lvl, blk, kSmemFwdBytes, s, *e, parity);
         NDP_EV();

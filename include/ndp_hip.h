@@ -279,7 +279,9 @@ typedef struct ndp_engine {
                                         Measured variants kept behind bits: 64 the Adam step by the last-arriving
                                         backward workgroup of a pair (no k_eng_update launch; gmax must then be [2 B]); 128 the 4-wave
                                         shapes of the nearest-neighbour kernels; 256 a persistent one-launch tick for a handful of
-                                        resident pairs (k_eng_tick_small; gmax [2 B]) -- all bitwise the default, all slower.
+                                        resident pairs (k_eng_tick_small; gmax [2 B]) -- all bitwise the default, all slower;
+                                        512 the per-point warp of the split forward as a launch of its own (k_eng_warp) instead of
+                                        behind the forward workgroup's tile loop (same arithmetic, same bits).
                                         nn_mode 0: one-pass kernel, distances on the vector pipe; 2: the same on the bf16 matrix pipe
                                         with exact re-evaluation (bit-identical, needs ndp_engine_nn_matrix_fits(n_cap)); 1: latency
                                         shape -- two passes in 64-query workgroups, S/64 + T/64 of them per pair -- for a handful of
