@@ -2064,6 +2064,23 @@ k_eng_update(ndp_engine e, int parity) {
     if ((ns.decision == NDP_DEC_IDLE) | (i >= e.P) | (ns.step_level < 0) | (ns.step_t < 0)) return;
     eng_update_param(e, b, ns, desc_at_level(e.desc, ns.step_level), i);
 }
+// The update stage when the fused backward has stepped the two 128 x 128 matrices behind its tile loop (bf_adam_in_tail: G == 1):
+// what is left -- [W0 | b0], b1, [b2 | Wh | bh] -- on a COMPACT grid (8 workgroups per pair at six heads instead of 136: the empty
+// ones of the full grid cost more than the step itself, 17 us at 256 pairs).  Same eng_update_param, every decision handled there.
+__host__ __device__ inline int upd_rest_count(int P) { const ndp_layer_desc dd = {NDP_W, 2, 0, 0, 0, 0.f}; return ndp_off_Wi(&dd, 1) + NDP_W + (P - ndp_off_bi(&dd, 2)); }
+extern "C" __global__ void __launch_bounds__(256)
+k_eng_update_rest(ndp_engine e, int parity) {
+    const int b = blockIdx.y;
+    const ndp_pair_state *nsp = e.state + (size_t)(parity ^ 1) * e.B + b;   // written by k_eng_loss this tick
+    ndp_pair_state ns;
+    ns.decision = nsp->decision; ns.step_level = nsp->step_level; ns.step_t = nsp->step_t;
+    const ndp_layer_desc dd = {NDP_W, 2, 0, 0, 0, 0.f};
+    const int n0 = ndp_off_Wi(&dd, 1);                              // [0, n0): W0 | b0
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int i = c < n0 ? c : (c < n0 + NDP_W ? ndp_off_bi(&dd, 1) + (c - n0) : ndp_off_bi(&dd, 2) + (c - n0 - NDP_W));
+    if ((ns.decision == NDP_DEC_IDLE) | (i >= e.P) | (ns.step_level < 0) | (ns.step_t < 0)) return;
+    eng_update_param(e, b, ns, desc_at_level(e.desc, ns.step_level), i);
+}
 
 #include "ndp_tick_small.inc"
 #include "ndp_generic.inc"
@@ -2724,7 +2741,7 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
     // bf16 kernels: one 8-wave workgroup per CU.  With all three of them on (mask 7) the engine is sized for that (G workgroups and G
     // partials per pair); in a mixed configuration they take half the fp32 grid and zero the partials they do not write.
     const dim3 g_fwd8(engine_g8(e), e->B);
-    if (e->gemm_mode < 0 || e->gemm_mode > 511) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1), 64 (the Adam step inside the fused backward)");
+    if (e->gemm_mode < 0 || e->gemm_mode > 2047) return fail(NDP_E_INVALID, "ndp_engine_run: gemm_mode is a mask of 1 (forward), 2 (bwd1), 4 (bwd2) on fp16 splits, 8 (the split forward keeps h0), 16 (bwd2 and bwd1 as two launches), 32 (the fused backward also writes dz1), 64 (the Adam step inside the fused backward), 128 / 256 / 512 / 1024 (see ndp_hip.h)");
     // both backward layers on the splits: ONE launch (k_eng_bwd_f, stage 3; stage 4 launches nothing) unless bit 16 asks for the two round-3 kernels
     // width / depth other than 128 / 3: the generic fp32 level kernels (csrc/ndp_generic.inc); gemm_mode selects nothing there
     const bool generic = gen_is_generic(e->desc);
@@ -2817,7 +2834,9 @@ static int engine_launch_ticks(const ndp_engine *e, int tick0, int n_ticks, hipS
         else if (e->gemm_mode & 2) hipLaunchKernelGGL(k_eng_bwd1_8, g_fwd8, dim3(512), kSmemBwd18Bytes, s, *e, parity);
         else hipLaunchKernelGGL(k_eng_bwd1, g_lvl, blk, kSmemBwdBytes, s, *e, parity);
         NDP_EV();
-        if (NDP_ST(5) && !(bwd_fused && (e->gemm_mode & 64))) hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
+        if (!NDP_ST(5) || (bwd_fused && (e->gemm_mode & 64))) {}
+        else if (bwd_fused && bf_adam_in_tail(*e)) hipLaunchKernelGGL(k_eng_update_rest, dim3((upd_rest_count(e->P) + 255) / 256, e->B), blk, 0, s, *e, parity);
+        else hipLaunchKernelGGL(k_eng_update, g_upd, blk, 0, s, *e, parity);
         NDP_EV();
 #undef NDP_ST
 #undef NDP_EV

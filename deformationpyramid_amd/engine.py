@@ -57,9 +57,9 @@ def resolve_modes(B, n_cap, t_cap, gemm_mode=None, nn_mode=None, nn_matrix=None)
     if gemm_mode is None:
         gemm_mode = DEFAULT_GEMM_MODE
     gemm_mode = int(gemm_mode)
-    if not 0 <= gemm_mode <= 1023:
+    if not 0 <= gemm_mode <= 2047:
         raise N.NdpError(f"gemm_mode must be a mask of 1 (forward) | 2 (bwd1) | 4 (bwd2) [| 8: the split forward also stores h0 | 16: "
-                         f"the split backward as two launches | 32: the fused backward also writes dz1 -- tests | 64: the Adam step inside the fused backward | 256: persistent small-batch tick | 512: the per-point warp as a launch of its own], got {gemm_mode}")
+                         f"the split backward as two launches | 32: the fused backward also writes dz1 -- tests | 64: the Adam step inside the fused backward | 256: persistent small-batch tick | 512: the per-point warp as a launch of its own | 1024: at G = 1 the Adam step of the two 128 x 128 matrices behind the fused backward's tile loop], got {gemm_mode}")
     fits2 = bool(lib.ndp_engine_nn_matrix_fits(n_cap))
     fits0 = bool(lib.ndp_engine_nn_onepass_fits(n_cap))
     if nn_mode is not None:

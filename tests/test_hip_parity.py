@@ -355,6 +355,22 @@ def test_engine_is_deterministic_and_G_independent_in_loss(dev, arith):
     assert abs(s1[0].loss - s3[0].loss) < 1e-5 * abs(s1[0].loss)
 
 
+def test_adam_behind_the_backward_is_bitwise_the_update_stage(dev):
+    """G = 1 (the 256-slot engines of bench.py): the fused backward steps the two 128 x 128 matrices behind its tile loop and the compact
+    update kernel the rest; gemm_mode bit 1024 keeps the whole step in k_eng_update.  Through Adam steps, early stops and level hand-overs
+    (fresh moments), with pairs finishing at different ticks: parameters, moments, points and states bit for bit."""
+    runs = []
+    for mode in (7, 7 | 1024):
+        eng, states, _ = _engine_vs_oracle(dev, "se3aa", K=0, S=300, T=280, m=3, iters=40, early_stop=True, w_cd=1.0, trunc=1e9, B=3, G=1,
+                                           ratio=0.01, gemm_mode=mode, nn_mode=2)
+        runs.append((eng, states))
+    (e0, s0), (e1, s1) = runs
+    assert [(s.level, s.total_steps, list(s.evals_per_level[:3])) for s in s0] == [(s.level, s.total_steps, list(s.evals_per_level[:3])) for s in s1]
+    assert any(s.total_steps < 3 * 40 for s in s0)                        # an early stop happened: the ADVANCE path (moments zeroed, no step) ran
+    for name in ("params", "adam_m", "adam_v", "pts"):
+        assert torch.equal(getattr(e0, name), getattr(e1, name)), name
+
+
 @pytest.mark.parametrize("G", [3, 4, 9, 10, 16, 32, 33])
 def test_update_folds_any_number_of_partials(dev, G):
     """The update kernel requests the G gradient partials in batches (<= 3: one by one, 4..9: eight at a clamped index, >= 10: 32 at a

@@ -49,7 +49,9 @@ def _run_tick_by_stages(dev, tag, gemm_mode, S, T, level, head_scale, G=None, w_
     # gemm_mode 7: the split forward does not store h0 (bwd1 recomputes it); bit 8 makes it store h0 for the comparisons below --
     # test_h0_is_recomputed... pins that the bit changes nothing else
     # + 32: the fused backward (one launch for both layers, dz1 in LDS) also writes dz1 to HBM, where the two-launch form leaves it
-    mode = gemm_mode if (gemm_mode & 7) != 7 else (gemm_mode | (0 if gemm_mode & 16 else 32) | (8 if keep_h0 else 0))
+    # + 1024: the whole Adam step in the update stage -- at G = 1 the default steps the two 128 x 128 matrices behind the fused backward's
+    # tile loop and writes no partial of them (bitwise the same state: test_adam_behind_the_backward_is_bitwise_the_update_stage)
+    mode = gemm_mode if (gemm_mode & 7) != 7 else (gemm_mode | 1024 | (0 if gemm_mode & 16 else 32) | (8 if keep_h0 else 0))
     eng = BatchedEngine(d, cfg, 1, n_cap=S, t_cap=T, device=dev, gemm_mode=mode, nn_mode=1, G=G)
     g = torch.Generator().manual_seed(3)
     src = (torch.rand(S, 3, generator=g) - 0.5).contiguous()
