@@ -94,15 +94,22 @@ def pmc_traffic(kernels, pairs):
     return None, None
 
 
-def stage_kernels(gemm_mode, nn_mode):
-    """The launches behind each of the six tick stages (N.TICK_KERNELS order) for an engine's modes."""
+def adam_in_tail(gemm_mode, G):
+    """G = 1 engines (round 6): the fused backward steps the two 128 x 128 matrices behind its tile loop (csrc/ndp_bwd_fused.inc:
+    bf_adam_in_tail), k_eng_update_rest the other parameters; gemm_mode bit 1024 keeps the whole step in k_eng_update."""
+    return G == 1 and (gemm_mode & 7) == 7 and not gemm_mode & (16 | 64 | 256 | 1024)
+
+
+def stage_kernels(gemm_mode, nn_mode, G=0):
+    """The launches behind each of the six tick stages (N.TICK_KERNELS order) for an engine's modes.  (The per-point warp of the split
+    forward runs behind that kernel's tile loop since round 6; gemm_mode bit 512 keeps it a launch of its own.)"""
     fused = bwd_fused(gemm_mode)
-    return {"k_eng_fwd": ["k_eng_fwd8", "k_eng_warp"] if gemm_mode & 1 else ["k_eng_fwd"],
+    return {"k_eng_fwd": (["k_eng_fwd8", "k_eng_warp"] if gemm_mode & 512 else ["k_eng_fwd8"]) if gemm_mode & 1 else ["k_eng_fwd"],
             "k_eng_nn": [{0: "k_eng_nn", 1: "k_eng_nn_lat" if gemm_mode & 128 else "k_eng_nn_lat8", 2: "k_eng_nn_mx" if gemm_mode & 128 else "k_eng_nn_mx8"}[nn_mode]],
             "k_eng_loss": ["k_eng_loss"],
             "k_eng_bwd2": ["k_eng_bwd_f"] if fused else (["k_eng_bwd2_8"] if gemm_mode & 4 else ["k_eng_bwd2"]),
             "k_eng_bwd1": [] if fused else (["k_eng_bwd1_8"] if gemm_mode & 2 else ["k_eng_bwd1"]),
-            "k_eng_update": ["k_eng_update"]}
+            "k_eng_update": ["k_eng_update_rest"] if adam_in_tail(gemm_mode, G) else ["k_eng_update"]}
 
 
 def bwd_fused(gemm_mode):
@@ -118,8 +125,9 @@ def roofline_report(model, pairs, B, config):
     prof, eng, preps, active = kernel_profile(model, pairs, B)
     S, T, n = preps[0].S, preps[0].T, preps[0].S + preps[0].K       # n: points through the MLP (landmarks + samples)
     P = eng.P
-    names = stage_kernels(eng.gemm_mode, eng.nn_mode)
+    names = stage_kernels(eng.gemm_mode, eng.nn_mode, eng.G)
     fused = bwd_fused(eng.gemm_mode)
+    tail = adam_in_tail(eng.gemm_mode, eng.G)
     if fused:                      # the empty stage's slot holds two event records back to back (~5 us), not a kernel: not part of the tick
         prof = {k: v for k, v in prof.items() if k != "k_eng_bwd1"}
     dom = max(prof, key=prof.get)
@@ -140,6 +148,21 @@ def roofline_report(model, pairs, B, config):
             "peak_is": ("dense fp16 MFMA peak / 3 (three fp16 partial products per fp32-equivalent product; rounds 2-3 priced six bf16 ones against / 6)" if split.get(dom)
                         else "fp32 MFMA = fp32 vector peak"),
             "avg_launch_ms": prof[dom], "pairs_per_launch": active, "algorithmic_flop_per_pair_launch": flops[dom]}
+    if tail and dom == "k_eng_bwd2":
+        # The dominant launch also carries the Adam step of 2 x 128 x 128 parameters per pair (p, m, v read and written: an HBM-bound
+        # tail of ~25 us that used to be most of k_eng_update).  `frac` above prices the WHOLE launch against the MFMA peak; for the
+        # contractions alone the same tick is timed once more with the step kept in k_eng_update (gemm_mode | 1024, bitwise the same state).
+        roof["adam_tail"] = {"bytes_per_pair": 6 * 4 * 2 * 128 * 128, "note": "k_eng_bwd_f steps W1 and W2 behind its tile loop at G = 1; "
+                             "k_eng_update_rest steps the other parameters"}
+        try:
+            m2 = Registration(model.config, gemm_mode=eng.gemm_mode | 1024, nn_mode=model.nn_mode, nn_matrix=model.nn_matrix)
+            prof2, eng2, _, active2 = kernel_profile(m2, pairs, B)
+            a2 = flops[dom] * active2 / (prof2[dom] * 1e-3) / 1e12
+            roof["adam_tail"].update({"contractions_only_ms": prof2[dom], "contractions_only_frac": a2 / peak_of[dom],
+                                      "update_stage_ms_without_tail": prof2["k_eng_update"], "tick_ms_without_tail": sum(v for k, v in prof2.items() if k != "k_eng_bwd1")})
+            del eng2, m2
+        except Exception as ex:                        # (a measurement aid: never fails the line)
+            roof["adam_tail"]["error"] = str(ex)
     if traffic:                                   # the other ceiling, for the record: HBM bytes/s of the same kernel vs 8 TB/s
         roof["hbm_tbps"] = traffic / (prof[dom] * 1e-3) / 1e12
         roof["hbm_frac"] = roof["hbm_tbps"] / 8.0
@@ -150,14 +173,14 @@ def roofline_report(model, pairs, B, config):
     # its algorithmic bytes -- G gradient partials + parameters, two moments read and written -- at 8 TB/s), summed, against the
     # measured tick.  The per-kernel table decides nothing here: a tie between two kernels cannot flip this fraction.
     ideal = {k: flops[k] * active / (peak_of[k] * 1e12) * 1e3 for k in ("k_eng_fwd", "k_eng_nn", "k_eng_bwd2", "k_eng_bwd1") if k in prof}
-    ideal["k_eng_update"] = (eng.G + 7) * 4 * P * active / 8e12 * 1e3
+    ideal["k_eng_update"] = ((6 if tail else eng.G + 7) * 4 * P) * active / 8e12 * 1e3   # (tail: the matrices' gradient never leaves the chip)
     ideal_ms = sum(ideal.values())
     return {"roofline": roof, "kernels_ms_per_tick": {"+".join(names[k]): v for k, v in prof.items()}, "kernel_rooflines": per_kernel,
             "tick": {"ms": tick_ms, "achieved_tflops": (algorithmic_flops(n, 0, P) + FLOP_NN_PAIR * S * T) * active / (tick_ms * 1e-3) / 1e12,
                      "ideal_ms": ideal_ms, "frac": ideal_ms / tick_ms,
                      "ideal_ms_by_stage": {"+".join(names[k]): v for k, v in ideal.items()},
                      "ideal_is": "sum over stages of algorithmic FLOP / peak of the stage's pipe (split level kernels: 2500 / 3 TFLOP/s; "
-                                 "nearest neighbours: 157.3), update: algorithmic bytes / 8 TB/s; loss / decision stage: 0"},
+                                 "nearest neighbours: 157.3), update (wherever it runs): algorithmic bytes / 8 TB/s; loss / decision stage: 0"},
             "engine_modes": {"gemm_mode": eng.gemm_mode, "nn_mode": eng.nn_mode, "G": eng.G}}
 
 
