@@ -248,7 +248,7 @@ typedef struct ndp_engine {
     float *ldmk_t;                   /* [B][n_cap][3]                                           */
     float *tgt;                      /* [B][t_cap][3]                                           */
     float *params;                   /* [B][m][p_stride]                                        */
-    float *gpart;                    /* [B][G][p_stride]                                        */
+    float *gpart;                    /* [B][G][p_stride] gradient partials (G == 1 without gemm_mode bit 1024: the W1 / W2 blocks are not written) */
     float *adam_m, *adam_v;          /* [B][p_stride]                                           */
     float *act;                      /* [B][3][n_cap][128] fp32 rows of h0, h1, h2 ([B][depth][n_cap][width] for other shapes) -- except under the default gemm_mode 7 (fused
                                         split backward), where planes 1 and 2 hold h1 and (since ABI 202) h2 per 64-point tile as a
@@ -281,7 +281,10 @@ typedef struct ndp_engine {
                                         shapes of the nearest-neighbour kernels; 256 a persistent one-launch tick for a handful of
                                         resident pairs (k_eng_tick_small; gmax [2 B]) -- all bitwise the default, all slower;
                                         512 the per-point warp of the split forward as a launch of its own (k_eng_warp) instead of
-                                        behind the forward workgroup's tile loop (same arithmetic, same bits).
+                                        behind the forward workgroup's tile loop (same arithmetic, same bits); 1024 the whole Adam
+                                        step in k_eng_update -- without it an engine with G == 1 steps the two 128 x 128 matrices
+                                        behind the fused backward's tile loop (no gradient partial of them is written: gpart's two
+                                        matrix blocks are then undefined) and the rest in k_eng_update_rest: bitwise the same state.
                                         nn_mode 0: one-pass kernel, distances on the vector pipe; 2: the same on the bf16 matrix pipe
                                         with exact re-evaluation (bit-identical, needs ndp_engine_nn_matrix_fits(n_cap)); 1: latency
                                         shape -- two passes in 64-query workgroups, S/64 + T/64 of them per pair -- for a handful of
