@@ -1,10 +1,4 @@
 cd $GRAFT_REPO_ROOT
-for c in B C D E; do
-  python bench.py --config $c --steps 2 --warmup 1 > gpurun_out/r06f_bench_config_$c.json 2> /dev/null
-done
-python bench.py --slots 64 --engines 1 --pairs-per-step 2048 --steps 2 --warmup 1 --no-alt --no-latency --no-cpu-baseline > gpurun_out/r06f_bench_batch64.json 2> /dev/null
-python -c "
-import json
-for c in 'BCDE':
-    e=json.load(open('gpurun_out/r06f_bench_config_%s.json'%c)); print(c, round(e['value'],1), e['roofline']['kernel'], round(e['roofline']['frac'],3), round(e['tick']['ms'],4))
-e=json.load(open('gpurun_out/r06f_bench_batch64.json')); print('batch64', round(e['value'],1))"
+mkdir -p gpurun_out/r06
+NDP_TICK_HASH=1 bash tools/experiments/ab.sh "x0 x1" 3 256 24 > gpurun_out/r06/ab_warp_tail2.txt 2>&1
+cat gpurun_out/r06/ab_warp_tail2.txt | cut -c1-200
