@@ -2390,7 +2390,7 @@ extern "C" int ndp_debug_phase_read(unsigned long long *out64, int reset) {
 #ifndef NDP_BUILD_ID
 #define NDP_BUILD_ID "unversioned"
 #endif
-extern "C" int ndp_version(void) { return 202; }           // 201: ndp_load_job gained n_src / n_tgt (88 bytes), `means` in/out; 202: h2 as a plane image under gemm_mode 7
+extern "C" int ndp_version(void) { return 203; }           // 201: ndp_load_job gained n_src / n_tgt (88 bytes), `means` in/out; 202: h2 as a plane image under gemm_mode 7; 203: gemm_mode bits 512 / 1024, at G == 1 the matrix blocks of gpart are not written
 extern "C" const char *ndp_last_error(void) { return g_err; }
 static const char k_build_tag[] = "NDP_BUILD_ID=" NDP_BUILD_ID;        // the loader finds this tag in the file without loading it
 extern "C" const char *ndp_build_id(void) { return k_build_tag + 13; }
