@@ -88,7 +88,7 @@ class _PinRing:
 
 class _BatchCtx:
     """What the lanes of one register_batch call share."""
-    __slots__ = ("reg", "preps", "next_prepared", "fin_stream", "main", "chunk", "m", "exhausted", "handed_out", "total_slots", "sink", "states")
+    __slots__ = ("reg", "preps", "next_prepared", "fin_stream", "main", "chunk", "m", "exhausted", "handed_out", "total_slots", "sink", "states", "fin_batches")
 
     def __init__(self, reg, preps, next_prepared, fin_stream, main, chunk, m):
         self.reg, self.preps, self.next_prepared = reg, preps, next_prepared
@@ -96,6 +96,7 @@ class _BatchCtx:
         self.exhausted = False
         self.handed_out, self.total_slots = 0, 0          # pairs given to lanes so far / slots of all lanes (set once they exist)
         self.sink = None
+        self.fin_batches = 0                              # final-warp batches handed to the sink so far
         self.states = [None] * len(preps)                 # final pair states by index (register_batch -> last_states)
 
 
@@ -184,6 +185,11 @@ class _Lane:
                             ctx.sink(p.index, p.result, p.state)
                             p.result = None
                             ctx.preps[p.index] = None                 # a long stream holds the resident pairs only (its states: ctx.states)
+                    # nobody waits on the final-warp stream in a sink stream (the sink's work is ordered on it): like the producers'
+                    # side streams it is synchronised now and then, or the HIP runtime's per-command state of it grows with the stream
+                    ctx.fin_batches += 1
+                    if ctx.fin_batches % 64 == 0:
+                        ctx.fin_stream.synchronize()
         self.pending = handle
 
 
