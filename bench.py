@@ -81,14 +81,26 @@ def pmc_traffic(kernels, pairs):
     and scaled linearly to this launch's pair count).  -> (bytes or None, source description or None): the figure is NOT
     measured in this run -- `traffic_source` names the committed profile it comes from and that file's git blob hash."""
     try:
-        names = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_hbm_traffic_pmc.json"))
-        for name in reversed(names):                                             # newest round that has these kernels
+        names = sorted(p for p in os.listdir(os.path.join(ROOT, "profiles")) if p.endswith("_pmc.json") and "_hbm_traffic" in p and "_mode" not in p and "2launch" not in p)
+        rnd = names[-1][:3] if names else ""                                     # newest round's files only
+        best = None
+        for name in names:
+            if not name.startswith(rnd):
+                continue
             path = os.path.join(ROOT, "profiles", name)
             rec = json.load(open(path))
             if all(k in rec for k in kernels):
-                tot = sum(rec[k]["hbm_bytes_per_launch"] * pairs / rec[k]["pairs_per_launch"] for k in kernels)
-                return tot, {"file": "profiles/" + name, "git_blob": _git_blob_hash(path), "kernels": list(kernels),
-                             "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_traffic.sh), FETCH_SIZE doubled"}
+                # the collection whose launch geometry is closest to this one (the 256-pair engines run G = 1: the backward carries the
+                # Adam tail there and not at 128 pairs), scaled linearly to the active pair count
+                d = max(abs(rec[k]["pairs_per_launch"] - pairs) for k in kernels)
+                if best is None or d < best[0]:
+                    best = (d, name, path, rec)
+        if best is not None:
+            _, name, path, rec = best
+            tot = sum(rec[k]["hbm_bytes_per_launch"] * pairs / rec[k]["pairs_per_launch"] for k in kernels)
+            return tot, {"file": "profiles/" + name, "git_blob": _git_blob_hash(path), "kernels": list(kernels),
+                         "pairs_per_launch_of_the_collection": rec[kernels[0]]["pairs_per_launch"],
+                         "how": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_traffic.sh), FETCH_SIZE doubled"}
     except (OSError, KeyError, ValueError, IndexError):
         pass
     return None, None

@@ -44,6 +44,9 @@ b.update(a)                       # kernels common to both (nn variants aside: u
 print(json.dumps(b, indent=1))
 PY
 NDP_GEMM_MODE=23 bash $R/tools/pmc_traffic.sh 128 8 > $O/${TAG}_hbm_traffic_2launch_pmc.json 2>> $O/${TAG}_hbm_traffic_pmc.err
+# the 256-pair tick (G = 1: the backward carries the Adam step of the two matrices) with and without that tail (gemm_mode | 1024)
+bash $R/tools/pmc_traffic.sh 256 8 > $O/${TAG}_hbm_traffic_256pairs_pmc.json 2>> $O/${TAG}_hbm_traffic_pmc.err
+NDP_GEMM_MODE=1031 bash $R/tools/pmc_traffic.sh 256 8 > $O/${TAG}_hbm_traffic_256pairs_mode1031_pmc.json 2>> $O/${TAG}_hbm_traffic_pmc.err
 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_pmc.json
 NDP_GEMM_MODE=23 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_2launch_pmc.json
 NDP_GEMM_MODE=0 NDP_NN_MODE=0 bash $R/tools/pmc_sq.sh 128 12 > /dev/null 2>&1; cp $O/pmc_sq.json $O/${TAG}_sq_counters_bitwise_pmc.json
