@@ -1,8 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r06
-{
-echo "# loss stage: head record + level input requested up front, pair state read field by field (no scratch copy): l0 = before, l1 = after"
-NDP_TICK_HASH=1 bash tools/experiments/ab.sh "l0 l1" 3 256 24
-for v in l0 l1 l0 l1; do echo "$v: $(NDP_HIP_LIB=$PWD/tools/experiments/var/$v.so python tools/latency_bench.py 6 2>&1 | grep 'six launches' | tail -1)"; done
-} > gpurun_out/r06/loss_hoist_ab.txt 2>&1
-cat gpurun_out/r06/loss_hoist_ab.txt
+python -m pytest tests/test_hip_parity.py -q -x -k "nn or neigh or chamfer or engine_matches or engine_nn or config5 or bench_cloud" 2>&1 | tail -2
+NDP_TICK_HASH=1 bash tools/experiments/ab.sh "n0 n1" 3 256 24 > gpurun_out/r06/ab_nn_onewg.txt 2>&1
+NDP_TICK_HASH=1 bash tools/experiments/ab.sh "n0 n1" 2 128 24 >> gpurun_out/r06/ab_nn_onewg.txt 2>&1
+cat gpurun_out/r06/ab_nn_onewg.txt | cut -c1-200
